@@ -1,0 +1,200 @@
+"""CPU restatement of the reference's DISGAT hot path.  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module; the product (edgedisentangle_ssl_amd/) never does.  It is the
+checker, never the thing measured or shipped.
+
+Parity status: PINNED.  tests/test_oracle_golden.py checks every function here
+against fixtures produced by oracle/gen_golden.py, which runs the unmodified
+reference (imported read-only from /root/reference in the build container).
+
+The functions are written functionally over plain tensors / state-dict style
+dicts (same key names as the reference's state_dict, models.py:165-179) and use
+the same per-head, per-edge formulation as the reference (gather -> concat ->
+matmul -> scatter-add), with two deliberate differences that do not change the
+result: (1) SageConv's row sum uses an O(E) scatter instead of adj.to_dense()
+(layers.py:103); (2) the index set is coalesced once instead of once per head
+(layers.py:344).  Everything is autograd-differentiable and dtype-generic
+(float64 is used as the arbiter in the tests).
+"""
+import torch
+import torch.nn.functional as F
+
+
+# ----------------------------------------------------------------------------- graph helpers
+def coalesced_indices(adj_or_indices, n=None):
+    """Row-major unique (row, col) set == adj.coalesce().indices() (layers.py:344)."""
+    if isinstance(adj_or_indices, torch.Tensor) and adj_or_indices.is_sparse:
+        return adj_or_indices.coalesce().indices()
+    idx = adj_or_indices
+    flat = torch.unique(idx[0] * n + idx[1])
+    return torch.stack([flat // n, flat % n])
+
+
+# ----------------------------------------------------------------------------- utils.py:192-207
+def sp_softmax(rows, values, n):
+    """utils.py:192-200: global-max shift, scatter-add over rows, +1e-10, divide."""
+    ex = torch.exp(values - values.max())
+    denom = torch.zeros(n, values.shape[1], dtype=values.dtype).index_add_(0, rows, ex)
+    denom = denom + 1e-10
+    return ex / denom[rows]
+
+
+def sp_matmul(rows, cols, values, mat):
+    """utils.py:203-207: out[row] += value * mat[col]."""
+    out = torch.zeros_like(mat)
+    return out.index_add(0, rows, values * mat[cols])
+
+
+# ----------------------------------------------------------------------------- layers.py:349-389
+def pair_score(att, x, W, a, r, c):
+    """Raw (pre-sigmoid) attention score of node pairs (r_k, c_k); [K,1]."""
+    if att == 1:                                   # layers.py:349-353 (no nonlinearity)
+        h = x @ W
+        return torch.cat([h[r], h[c]], dim=1) @ a
+    if att == 2:                                   # layers.py:362-365 (unscaled dot product)
+        h = x @ W
+        return (h[r] * h[c]).sum(-1, keepdim=True)
+    if att == 3:                                   # layers.py:374-379 (leaky_relu slope 0.01)
+        z = torch.cat([x[r], x[c]], dim=1) @ W
+        return F.leaky_relu(z) @ a
+    raise ValueError(att)
+
+
+def disga_layer(x, ei, p, att, gnn, aux=None, pre=""):
+    """One DisGALayer head (layers.py:340-416, 493-511).
+
+    p: dict with keys pre+{'W','a'} and 'W_em' | 'ag_layer.proj.weight' |
+    'ag_layer.weight','ag_layer.bias'.  Returns (elu(h'), edge_e[E,1], [aux_e]).
+    """
+    n = x.shape[0]
+    r, c = ei[0], ei[1]
+    W, a = p[pre + "W"], p[pre + "a"]
+    e = pair_score(att, x, W, a, r, c)
+    aux_e = None
+    if aux is not None:
+        aux_e = [pair_score(att, x, W, a, ai[0], ai[1]) for ai in aux]
+    att_w = sp_softmax(r, torch.sigmoid(e), n)     # layers.py:392-393
+    if gnn == "AT":                                # layers.py:397-399
+        h = sp_matmul(r, c, att_w, x @ p[pre + "W_em"])
+    elif gnn == "SAGE":                            # layers.py:400-403 + SageConv.forward :96-110
+        rowsum = torch.zeros(n, 1, dtype=x.dtype).index_add_(0, r, att_w.detach())
+        neigh = sp_matmul(r, c, att_w, x) / (rowsum + 1)
+        h = torch.cat([x, neigh], dim=-1) @ p[pre + "ag_layer.proj.weight"].t()
+    elif gnn == "GCN":                             # layers.py:404-407 + GraphConvolution.forward :38-54
+        h = sp_matmul(r, c, att_w, x @ p[pre + "ag_layer.weight"]) + p[pre + "ag_layer.bias"]
+    else:
+        raise ValueError(gnn)
+    return F.elu(h), e, aux_e
+
+
+# ----------------------------------------------------------------------------- layers.py:896-921
+def fuse_layer(p, heads, residue=None, residue_type=0, fuse_no_relu=False, residue_dim=0, pre=""):
+    f = torch.cat(heads, dim=-1)
+    use_res = residue_dim != 0 and residue is not None
+    lin = lambda name, t: t @ p[pre + name + ".weight"].t() + p[pre + name + ".bias"]
+    if residue_type == 0:
+        if use_res:
+            f = torch.cat([f, residue], dim=-1)
+        out = lin("fuse", f)
+    elif residue_type == 1:
+        if use_res:
+            f = torch.cat([f, residue], dim=-1)
+        out = lin("fuse2", F.leaky_relu(lin("fuse", f)))
+    else:
+        out = lin("fuse", f)
+        if use_res:
+            out = out + lin("fuse2", residue)
+    return out if fuse_no_relu else F.leaky_relu(out)
+
+
+# ----------------------------------------------------------------------------- models.py:523-543
+def mlp(p, x, cls=False, pre=""):
+    """Linear -> LeakyReLU(0.1) -> ... -> Linear (+ log_softmax)."""
+    keys = sorted({int(k[len(pre):].split(".")[1]) for k in p if k.startswith(pre + "model.")})
+    for i, k in enumerate(keys):
+        x = x @ p[f"{pre}model.{k}.weight"].t() + p[f"{pre}model.{k}.bias"]
+        if i + 1 < len(keys):
+            x = F.leaky_relu(x, 0.1)
+    return F.log_softmax(x, dim=1) if cls else x
+
+
+# ----------------------------------------------------------------------------- models.py:181-373
+def disgat_pass(sd, x, ei, fusers, nheads, att, gnn, aux=None):
+    """The common two-layer loop behind all five DISGAT entry points (dropout 0).
+
+    fusers: two callables f(list_of_heads, residue).  Returns a dict with
+    feat (2 x [N,nhid]), adjs (2 x H x [E,1]), aux (2 x H x list), edge_em
+    (2 x H x [N,F_l+nhid]).
+    """
+    res = {"feat": [], "adjs": [], "aux": [], "edge_em": []}
+    cur = x
+    for layer in (1, 2):
+        heads, adjs, auxs, eem = [], [], [], []
+        for i in range(nheads):
+            h, e, au = disga_layer(cur, ei, sd, att, gnn, aux, pre=f"attention{layer}_{i}.")
+            heads.append(h)
+            adjs.append(e)
+            auxs.append(au)
+            eem.append(torch.cat((cur, h), dim=-1))           # models.py:347, 365
+        cur = fusers[layer - 1](heads, cur)
+        res["feat"].append(cur)
+        res["adjs"].append(adjs)
+        res["aux"].append(auxs)
+        res["edge_em"].append(eem)
+    return res
+
+
+def disgat_forward(sd, x, ei, fusers, nheads, att, gnn):
+    return F.log_softmax(disgat_pass(sd, x, ei, fusers, nheads, att, gnn)["feat"][1], dim=1)  # models.py:214
+
+
+# ----------------------------------------------------------------------------- utils.py:287-298
+def adj_mse_loss(rec, tgt):
+    """Class-reweighted MSE, including the 1-D quirk: total = shape[0]**2."""
+    edge_num = int((tgt != 0).sum())
+    total = tgt.shape[0] ** 2
+    neg_w = edge_num / (total - edge_num)
+    w = torch.where(tgt == 0, torch.full_like(rec, neg_w), torch.ones_like(rec))
+    return torch.mean(w * (rec - tgt) ** 2)
+
+
+def _layer_on(constrain_layer, i):
+    return constrain_layer == 0 or constrain_layer == i          # pretrainer.py:597, 728
+
+
+def sup_edge_loss(aux, labels, constrain_layer=0):
+    """pretrainer.py:727-739.  aux = disgat_pass(...)['aux'] with ONE aux list."""
+    loss = None
+    for i, layer in enumerate(aux):
+        if _layer_on(constrain_layer, i):
+            pred = torch.sigmoid(torch.stack([h[0] for h in layer]).sum(0))
+            term = adj_mse_loss(pred.squeeze(), labels)
+            loss = term if loss is None else loss + term
+    return loss
+
+
+def dis_edge_loss(aux, labels_homo, labels_het, constrain_layer=0):
+    """pretrainer.py:612-627.  aux lists: [0]=homo pairs, [1]=hetero pairs; the
+    first H/2 heads are supervised on list 0, the last H/2 on list 1."""
+    loss = None
+    for i, layer in enumerate(aux):
+        if _layer_on(constrain_layer, i):
+            half = int(len(layer) / 2)
+            p_ho = torch.sigmoid(torch.stack([h[0] for h in layer[:half]]).sum(0))
+            p_he = torch.sigmoid(torch.stack([h[1] for h in layer[half:]]).sum(0))
+            term = adj_mse_loss(p_ho.squeeze(), labels_homo) + adj_mse_loss(p_he.squeeze(), labels_het)
+            loss = term if loss is None else loss + term
+    return loss
+
+
+def dif_head_loss(edge_em, cls1, cls2):
+    """pretrainer.py:819-832: per layer, per head i: NLL(log_softmax(MLP(cat(in,out_i))), i)."""
+    loss = None
+    for layer, embeds in enumerate(edge_em):
+        p = cls1 if layer == 0 else cls2
+        for i, e in enumerate(embeds):
+            lp = mlp(p, e, cls=True)
+            term = -lp[:, i].mean()
+            loss = term if loss is None else loss + term
+    return loss

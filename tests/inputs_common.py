@@ -1,0 +1,140 @@
+"""Deterministic input builders shared by oracle/gen_golden.py and the tests.
+
+Everything here is pure numpy (PCG64 streams are stable across numpy versions),
+so a fixture only has to record a seed plus the EXPECTED OUTPUTS; the inputs and
+parameters are rebuilt bit-identically on the test side.  Nothing in this file
+touches /root/reference or oracle/.
+"""
+import zlib
+
+import numpy as np
+import torch
+
+
+def _rng(seed, tag=""):
+    return np.random.Generator(np.random.PCG64([int(seed), zlib.crc32(tag.encode())]))
+
+
+def make_params(shapes, seed):
+    """shapes: ordered dict name -> shape (a module's state_dict layout).
+
+    Returns name -> float32 torch tensor.  Scale mimics the reference
+    initialisers (layers.py:319-337 xavier gain 1.414; layers.py:79 N(0,1) for
+    SageConv.proj; layers.py:33-36 uniform(+-1/sqrt(F_out)) for GraphConvolution;
+    nn.Linear defaults elsewhere) without using torch's RNG.
+    """
+    out = {}
+    for name, shape in shapes.items():
+        shape = tuple(int(s) for s in shape)
+        g = _rng(seed, name)
+        if name.endswith("ag_layer.proj.weight"):
+            v = g.standard_normal(shape)
+        elif len(shape) == 2:
+            fan = shape[0] + shape[1]
+            v = g.standard_normal(shape) * (1.414 * np.sqrt(2.0 / fan))
+        else:
+            v = g.uniform(-0.1, 0.1, shape)
+        out[name] = torch.from_numpy(v.astype(np.float32))
+    return out
+
+
+def load_params(module, seed):
+    """Fill module's state_dict with make_params(seed) values (in place)."""
+    sd = module.state_dict()
+    shapes = {k: tuple(v.shape) for k, v in sd.items()}
+    module.load_state_dict(make_params(shapes, seed))
+    return module
+
+
+def tiny_graph(seed=11, n=64, n_und=170):
+    """Small symmetric graph with self loops, one hub row, degree-1 rows, one
+    isolated node (no self loop -> degree-0 row), duplicate COO entries and a
+    shuffled (uncoalesced) entry order.  Returns (indices int64 [2,nnz_raw],
+    values float32 [nnz_raw], n)."""
+    g = _rng(seed, "tiny_graph")
+    r = g.integers(0, n - 1, n_und)
+    c = g.integers(0, n - 1, n_und)
+    hub = 3
+    hub_nb = g.choice(n - 1, 40, replace=False)
+    r = np.concatenate([r, np.full(40, hub)])
+    c = np.concatenate([c, hub_nb])
+    a = np.zeros((n, n), dtype=bool)
+    a[r, c] = True
+    a |= a.T
+    a[np.arange(n), np.arange(n)] = True
+    lonely = [5, 9]              # self loop only -> degree-1 rows
+    for v in lonely:
+        a[v, :] = False
+        a[:, v] = False
+        a[v, v] = True
+    a[n - 1, :] = False          # isolated: degree-0 row and column
+    a[:, n - 1] = False
+    rows, cols = np.nonzero(a)
+    # duplicates: repeat the first 7 entries once more
+    rows = np.concatenate([rows, rows[:7]])
+    cols = np.concatenate([cols, cols[:7]])
+    perm = g.permutation(rows.shape[0])
+    rows, cols = rows[perm], cols[perm]
+    vals = g.uniform(0.05, 1.0, rows.shape[0]).astype(np.float32)
+    idx = torch.from_numpy(np.stack([rows, cols]).astype(np.int64))
+    return idx, torch.from_numpy(vals), n
+
+
+def features(seed, n, f, kind="randn"):
+    g = _rng(seed, "features_" + kind)
+    if kind == "randn":
+        x = g.standard_normal((n, f))
+    elif kind == "cora_surrogate":
+        # non-negative, sparse-ish bag-of-words-like rows, row-sum normalised
+        # (data_load.py:137-144 normalises by the row sum); SURVEY 8c.
+        x = (g.random((n, f)) < 0.15) * g.random((n, f))
+        x[np.arange(n), g.integers(0, f, n)] += 0.5     # no empty row
+        x = x / x.sum(1, keepdims=True)
+    else:
+        raise ValueError(kind)
+    return torch.from_numpy(x.astype(np.float32))
+
+
+def aux_pairs(seed, n, m, tag="aux"):
+    """Row-major sorted random node pairs (the order of mask.nonzero(),
+    pretrainer.py:703), int64 [2,m]."""
+    g = _rng(seed, tag)
+    flat = np.sort(g.choice(n * n, size=m, replace=False))
+    return torch.from_numpy(np.stack([flat // n, flat % n]).astype(np.int64))
+
+
+def coalesced_index_set(indices, n):
+    """Unique (row, col) pairs in row-major order == adj.coalesce().indices()."""
+    flat = torch.unique(indices[0] * n + indices[1])
+    return torch.stack([flat // n, flat % n])
+
+
+def sample_pairs(seed, n, pos_flat, tag="pairs"):
+    """O(E) statistical equivalent of the reference's sparse SSL samplers
+    (pretrainer.py:683-707, 524-576): Bernoulli(3*rho) over all n^2 entries
+    united with a random third of the positives, returned in row-major order
+    with 0/1 labels = membership in the positive set.
+
+    pos_flat: sorted unique int64 numpy array of row*n+col of the positives.
+    Returns (indices int64 [2,M] torch, labels float32 [M] torch)."""
+    g = _rng(seed, tag)
+    npos = int(pos_flat.shape[0])
+    m_rand = 3 * npos
+    rand_flat = g.integers(0, n * n, m_rand)
+    sel = g.permutation(npos)[: npos // 3]
+    flat = np.unique(np.concatenate([rand_flat, pos_flat[sel]]))
+    labels = np.isin(flat, pos_flat).astype(np.float32)
+    idx = np.stack([flat // n, flat % n]).astype(np.int64)
+    return torch.from_numpy(idx), torch.from_numpy(labels)
+
+
+def edge_sets(edge_index, labels, n):
+    """Flat (row*n+col) positive sets for SupEdge (all edges) and DisEdge
+    (homo = edge & same label, hetero = edge & different label;
+    pretrainer.py:448-456)."""
+    r = edge_index[0].numpy()
+    c = edge_index[1].numpy()
+    lab = labels.numpy()
+    flat = r.astype(np.int64) * n + c
+    same = lab[r] == lab[c]
+    return np.sort(flat), np.sort(flat[same]), np.sort(flat[~same])
