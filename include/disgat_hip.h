@@ -1,0 +1,95 @@
+/*
+ * disgat_hip.h - C ABI of libdisgat_hip.so: the MI355X (gfx950) implementation of the
+ * DISGAT edge-disentangled message-passing hot path.
+ *
+ * Every entry point is a stateless launcher: plain device pointers and sizes, no
+ * framework types, the caller owns every buffer, work is enqueued on the given HIP
+ * stream and the call returns without synchronising.  Return value: 0 = launched,
+ * >0 = hipError_t from the runtime, <0 = argument outside the kernel envelope
+ * (disgat_last_error() gives the text).  The Python host (edgedisentangle_ssl_amd/_lib.py)
+ * binds these with ctypes and raises RuntimeError on a non-zero return.
+ *
+ * What each launcher replaces in the reference (/root/reference, Python/ATen):
+ *
+ *  disgat_edge_fwd      DisGALayer.forward_sparse for ALL heads of one layer at once:
+ *                       per-edge score (layers.py:349-379), sigmoid (layers.py:392),
+ *                       utils.sp_softmax (utils.py:192-200) and the weighted neighbour
+ *                       aggregation utils.sp_matmul (utils.py:203-207) used by the AT /
+ *                       SAGE / GCN branches (layers.py:397-407, 96-110, 38-54).
+ *  disgat_edge_combine  second pass for rows that were split across work items (no
+ *                       reference counterpart: load balancing for power-law rows).
+ *  disgat_aux_score     the auxiliary node-pair scoring of predict_adjs_sparse
+ *                       (layers.py:355-360, 368-372, 381-389; models.py:290-330).
+ *  disgat_edge_bwd_*    autograd of the above (the reference relies on ATen autograd of
+ *                       index/cat/mm/scatter_add_; loss.backward() at pretrainer.py:752).
+ *  disgat_pair_loss     sigmoid(sum of heads) + utils.adj_mse_loss partial sums
+ *                       (pretrainer.py:727-739, 612-627; utils.py:287-298).
+ *
+ * Layouts (all row-major fp32 unless noted; "ld*" = row stride in floats, a multiple of 4,
+ * base pointers 16-byte aligned):
+ *   items   int32 [n_items][4] = {row, e_begin, e_end, slot}; slot = -1 for a whole row,
+ *           else the index of this chunk's partial record (split rows)
+ *   col     int32 [E]   CSR column (= the reference's indices[1], "target": the gathered node)
+ *   x       [N][ldx]    layer input, F_in valid columns (F_in % 4 == 0 after padding)
+ *   Z       [N][H][F_in] attention-weighted neighbour sums  sum_k alpha_k * x[col_k]
+ *   edge_e  [H][E]      raw pre-sigmoid scores in CSR (= coalesced, row-major) edge order
+ *   den     [N][H]      softmax denominators sum_k exp(sigmoid(e_k)) (saved for backward)
+ *   H must be a power of two (the host pads missing heads with zero weights).
+ *
+ * att (the reference's --att / att_type):
+ *   1  e = s1[row][h] + s2[col][h]                     rowop = s1 [N][H], colop = s2 [N][H]
+ *   2  e = <P[row][h][:], x[col][:]>                   rowop = P [N][H*F_in]  (P = x W W^T)
+ *   3  e = sum_f a[h][f]*lrelu_0.01(P[row][h][f] + Q[col][h][f])
+ *                                                      rowop = P, colop = Q [N][H*F_out], a [H*F_out]
+ *      F_out must equal QN*(64/H)*4 with QN in {1,2,4,8} (host pads with zero columns).
+ */
+#ifndef DISGAT_HIP_H
+#define DISGAT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* disgat_stream_t; /* hipStream_t */
+
+int disgat_abi_version(void);
+const char* disgat_last_error(void);
+
+/* Fused score -> sigmoid -> row softmax -> aggregation for all H heads of one layer. */
+int disgat_edge_fwd(int att, const int32_t* items, int n_items, const int32_t* col, int64_t E,
+                    int N, int H, int F_in, int F_out,
+                    const float* x, int ldx,
+                    const float* rowop, int ld_row,
+                    const float* colop, int ld_col,
+                    const float* a,
+                    float* Z, float* edge_e, float* den,
+                    float* part_z, float* part_den,
+                    int sage_div,
+                    disgat_stream_t stream);
+
+/* Sums the partial records of split rows (in chunk order: deterministic) and normalises. */
+int disgat_edge_combine(const int32_t* split_rows, const int32_t* split_ptr, int n_split,
+                        int H, int F_in, const float* part_z, const float* part_den,
+                        float* Z, float* den, int sage_div, disgat_stream_t stream);
+
+/* Raw scores of M arbitrary node pairs, heads [h_lo, h_hi) only; out is [H][M]. */
+int disgat_aux_score(int att, const int64_t* pair_rows, const int64_t* pair_cols, int64_t M,
+                     int N, int H, int F_in, int F_out, int h_lo, int h_hi,
+                     const float* x, int ldx,
+                     const float* rowop, int ld_row,
+                     const float* colop, int ld_col,
+                     const float* a,
+                     float* out, disgat_stream_t stream);
+
+/* Weighted squared-error partial sums of pred = sigmoid(sum_{h in [h_lo,h_hi)} aux[h][m])
+ * against 0/1 labels: acc[0] += sum over positives, acc[1] += sum over zeros, acc[2] += #positives.
+ * acc (3 doubles) must be zeroed by the caller. */
+int disgat_pair_loss(const float* aux, int64_t M, int h_lo, int h_hi, const float* labels,
+                     double* acc, disgat_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DISGAT_HIP_H */
