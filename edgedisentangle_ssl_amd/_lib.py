@@ -1,0 +1,123 @@
+"""Loader / builder for libdisgat_hip.so (the C ABI declared in include/disgat_hip.h).
+
+The library is built in-tree with hipcc for gfx950 and bound with ctypes: plain
+pointers and sizes only, no torch types cross the boundary.  There is NO CPU or
+PyTorch fallback: if the library is missing or a launcher reports an error the
+caller gets a RuntimeError.
+"""
+import ctypes
+import os
+import shutil
+import subprocess
+from concurrent.futures import ThreadPoolExecutor
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(_HERE, "libdisgat_hip.so")
+SOURCES = ["api_common.hip", "edge_fwd.hip", "aux_score.hip", "edge_bwd.hip"]
+ARCH = "gfx950"
+
+_lib = None
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: cannot build libdisgat_hip.so")
+
+
+def _stale():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(_HERE, "..", "include", "disgat_hip.h")]
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP source for gfx950 and link libdisgat_hip.so in-tree."""
+    if not force and not _stale():
+        return LIB_PATH
+    hipcc = _hipcc()
+    objdir = os.path.join(_HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+
+    def one(src):
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
+               "-c", os.path.join(CSRC, src), "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr[-4000:]}")
+        if verbose and r.stderr.strip():
+            print(r.stderr)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(4, len(srcs))) as ex:
+        objs = list(ex.map(one, srcs))
+    tmp = LIB_PATH + ".tmp"
+    r = subprocess.run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", tmp, *objs],
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
+    os.replace(tmp, LIB_PATH)
+    return LIB_PATH
+
+
+_c = ctypes
+_P = _c.c_void_p
+_SIGS = {
+    "disgat_abi_version": (_c.c_int, []),
+    "disgat_last_error": (_c.c_char_p, []),
+    "disgat_edge_fwd": (_c.c_int, [_c.c_int, _P, _c.c_int, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
+                                   _P, _c.c_int, _P, _c.c_int, _P, _c.c_int, _P, _P, _P, _P, _P, _P, _c.c_int, _P]),
+    "disgat_edge_combine": (_c.c_int, [_P, _P, _c.c_int, _c.c_int, _c.c_int, _P, _P, _P, _P, _c.c_int, _P]),
+    "disgat_aux_score": (_c.c_int, [_c.c_int, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
+                                    _c.c_int, _P, _c.c_int, _P, _c.c_int, _P, _c.c_int, _P, _P, _P]),
+    "disgat_pair_loss": (_c.c_int, [_P, _c.c_int64, _c.c_int, _c.c_int, _P, _P, _P]),
+    "disgat_edge_bwd": (_c.c_int, [_c.c_int, _P, _c.c_int, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
+                                   _P, _c.c_int, _P, _c.c_int, _P, _c.c_int, _P,
+                                   _P, _P, _P, _P, _P,
+                                   _P, _P, _P, _P, _P, _c.c_int, _P]),
+    "disgat_edge_bwd_col": (_c.c_int, [_c.c_int, _P, _P, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
+                                       _P, _c.c_int, _P, _c.c_int, _P, _c.c_int, _P,
+                                       _P, _P, _P, _P, _P, _c.c_int, _P]),
+    "disgat_aux_bwd": (_c.c_int, [_c.c_int, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
+                                  _c.c_int, _P, _c.c_int, _P, _c.c_int, _P, _c.c_int, _P, _P,
+                                  _P, _P, _P, _P, _P]),
+}
+
+
+def exported_symbols():
+    """Names include/disgat_hip.h declares (checked by the CPU test-suite)."""
+    return sorted(_SIGS)
+
+
+def load():
+    """dlopen the in-tree library (building it first if sources are newer)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if _stale():
+        build()
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            continue
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    """Invoke a launcher; raise RuntimeError with the library's message on failure."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        msg = lib.disgat_last_error()
+        raise RuntimeError(f"{name} failed (rc={rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,290 @@
+// Auxiliary node-pair scoring + pair-loss partial sums for gfx950.
+//
+// Replaces the aux branch of DisGALayer.forward_sparse (layers.py:355-360, 368-372, 381-389)
+// for all heads at once: the same score formula as the edge pass, evaluated on an arbitrary
+// int64 (2,M) pair list (pairs need not be edges; the reference's samplers emit them in
+// row-major order, pretrainer.py:703).  One wave64 per 64 consecutive pairs; the row-side
+// operand stays in registers while consecutive pairs share their row (sorted lists: ~M/N
+// pairs per row), the column-side operand is gathered per pair with a 2-deep pipeline.
+// Only heads [h_lo, h_hi) are evaluated: DisEdge supervises the first H/2 heads on the homo
+// list and the last H/2 on the hetero list (pretrainer.py:619-620), so half the gather is
+// skipped there.  Output layout [H][M] (each head contiguous = the reference's [M,1] tensors).
+#include "disgat_common.h"
+
+namespace disgat {
+
+struct AuxArgs {
+  const int64_t* pr;
+  const int64_t* pc;
+  int64_t M;
+  int N, F_in;
+  int h_lo, h_hi;
+  const float* x;
+  int ldx;
+  const float* rowop;
+  int ld_row;
+  const float* colop;
+  int ld_col;
+  const float* a;
+  float* out;
+};
+
+// att 3: lane = (head, g) exactly as in edge_fwd_kernel<3,...>.
+template <int HL, int QN>
+__global__ __launch_bounds__(DISGAT_BLOCK, 2) void aux_att3_kernel(const AuxArgs A) {
+  constexpr int GL = 6 - HL;
+  constexpr int G = 1 << GL;
+  constexpr int FQ = QN * G * 4;
+  const int lane = threadIdx.x & 63;
+  const int64_t m0 = ((int64_t)blockIdx.x * DISGAT_WAVES_PER_BLOCK + (threadIdx.x >> 6)) * 64;
+  if (m0 >= A.M) return;
+  const int cnt = (int)min((int64_t)64, A.M - m0);
+  const int myh = lane >> GL;
+  const bool active = (myh >= A.h_lo) && (myh < A.h_hi);
+  const int qoff = myh * FQ + (lane & (G - 1)) * 4;
+  const int rv = (lane < cnt) ? (int)A.pr[m0 + lane] : 0;
+  const int cv = (lane < cnt) ? (int)A.pc[m0 + lane] : 0;
+
+  f32x4 a_r[QN], p_r[QN], qA[QN], qB[QN];
+#pragma unroll
+  for (int j = 0; j < QN; ++j) {
+    a_r[j] = active ? ld4(A.a + qoff + j * G * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    p_r[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  int cur_r = -1;
+
+  auto load_q = [&](f32x4(&q)[QN], int c) {
+    if (active) {
+      const float* qp = A.colop + (size_t)c * A.ld_col + qoff;
+#pragma unroll
+      for (int j = 0; j < QN; ++j) q[j] = ld4(qp + j * G * 4);
+    }
+  };
+  auto compute = [&](const f32x4(&q)[QN], int i) {
+    const int r = __builtin_amdgcn_readlane(rv, i);
+    if (r != cur_r) {  // wave-uniform
+      cur_r = r;
+      if (active) {
+        const float* pp = A.rowop + (size_t)r * A.ld_row + qoff;
+#pragma unroll
+        for (int j = 0; j < QN; ++j) p_r[j] = ld4(pp + j * G * 4);
+      }
+    }
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < QN; ++j) acc = dot4_lrelu(a_r[j], p_r[j], q[j], acc);
+    acc = group_sum<GL>(acc);
+    if (active && (lane & (G - 1)) == 0) A.out[(int64_t)myh * A.M + m0 + i] = acc;
+  };
+
+  load_q(qA, __builtin_amdgcn_readlane(cv, 0));
+  int i = 0;
+  for (; i + 1 < cnt; i += 2) {
+    load_q(qB, __builtin_amdgcn_readlane(cv, i + 1));
+    compute(qA, i);
+    if (i + 2 < cnt) load_q(qA, __builtin_amdgcn_readlane(cv, i + 2));
+    compute(qB, i + 1);
+  }
+  if (i < cnt) compute(qA, i);
+}
+
+// att 2: e = <P[row][h][:], x[col][:]>, coalesced x mapping (lane*4 floats), head of a lane = lane % H.
+template <int HL, int XN>
+__global__ __launch_bounds__(DISGAT_BLOCK, 2) void aux_att2_kernel(const AuxArgs A) {
+  constexpr int H = 1 << HL;
+  const int lane = threadIdx.x & 63;
+  const int64_t m0 = ((int64_t)blockIdx.x * DISGAT_WAVES_PER_BLOCK + (threadIdx.x >> 6)) * 64;
+  if (m0 >= A.M) return;
+  const int cnt = (int)min((int64_t)64, A.M - m0);
+  const int myh = lane & (H - 1);
+  const int xoff = lane * 4;
+  const int rv = (lane < cnt) ? (int)A.pr[m0 + lane] : 0;
+  const int cv = (lane < cnt) ? (int)A.pc[m0 + lane] : 0;
+  f32x4 p_r[H * XN], xA[XN], xB[XN];
+#pragma unroll
+  for (int j = 0; j < H * XN; ++j) p_r[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int cur_r = -1;
+
+  auto load_x = [&](f32x4(&xv)[XN], int c) {
+    const float* xp = A.x + (size_t)c * A.ldx + xoff;
+#pragma unroll
+    for (int t = 0; t < XN; ++t) xv[t] = (t * 256 + xoff < A.F_in) ? ld4(xp + t * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  auto compute = [&](const f32x4(&xv)[XN], int i) {
+    const int r = __builtin_amdgcn_readlane(rv, i);
+    if (r != cur_r) {
+      cur_r = r;
+      const float* pp = A.rowop + (size_t)r * A.ld_row;
+#pragma unroll
+      for (int hh = 0; hh < H; ++hh)
+        if (hh >= A.h_lo && hh < A.h_hi) {
+#pragma unroll
+          for (int t = 0; t < XN; ++t) {
+            const int o = t * 256 + xoff;
+            p_r[hh * XN + t] = (o < A.F_in) ? ld4(pp + hh * A.F_in + o) : f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+        }
+    }
+    float e = 0.f;
+#pragma unroll
+    for (int hh = 0; hh < H; ++hh)
+      if (hh >= A.h_lo && hh < A.h_hi) {
+        float acc = 0.f;
+#pragma unroll
+        for (int t = 0; t < XN; ++t) acc = dot4(p_r[hh * XN + t], xv[t], acc);
+        acc = group_sum<6>(acc);
+        e = (myh == hh) ? acc : e;
+      }
+    if (lane < H && myh >= A.h_lo && myh < A.h_hi) A.out[(int64_t)myh * A.M + m0 + i] = e;
+  };
+
+  load_x(xA, __builtin_amdgcn_readlane(cv, 0));
+  int i = 0;
+  for (; i + 1 < cnt; i += 2) {
+    load_x(xB, __builtin_amdgcn_readlane(cv, i + 1));
+    compute(xA, i);
+    if (i + 2 < cnt) load_x(xA, __builtin_amdgcn_readlane(cv, i + 2));
+    compute(xB, i + 1);
+  }
+  if (i < cnt) compute(xA, i);
+}
+
+// att 1: e = s1[row][h] + s2[col][h]; one thread per pair, head loop inside (writes coalesced per head).
+__global__ __launch_bounds__(256) void aux_att1_kernel(const AuxArgs A) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; m < A.M; m += stride) {
+    const float* s1 = A.rowop + (size_t)A.pr[m] * A.ld_row;
+    const float* s2 = A.colop + (size_t)A.pc[m] * A.ld_col;
+    for (int h = A.h_lo; h < A.h_hi; ++h) A.out[(int64_t)h * A.M + m] = s1[h] + s2[h];
+  }
+}
+
+// pred = sigmoid(sum_{h in [h_lo,h_hi)} aux[h][m]); squared error against 0/1 labels, split by
+// label so the host can apply adj_mse_loss's class weights (utils.py:287-298):
+//   acc[0] += sum_{t!=0} (pred-t)^2, acc[1] += sum_{t==0} (pred-t)^2, acc[2] += #{t!=0}
+__global__ __launch_bounds__(256) void pair_loss_kernel(const float* __restrict__ aux, int64_t M, int h_lo, int h_hi,
+                                                        const float* __restrict__ labels, double* __restrict__ acc) {
+  double sp = 0.0, sn = 0.0, np_ = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += stride) {
+    float s = 0.f;
+    for (int h = h_lo; h < h_hi; ++h) s += aux[(int64_t)h * M + m];
+    const float t = labels[m];
+    const float d = sigmoidf_(s) - t;
+    if (t != 0.f) {
+      sp += (double)(d * d);
+      np_ += 1.0;
+    } else {
+      sn += (double)(d * d);
+    }
+  }
+  __shared__ double red[3][DISGAT_WAVES_PER_BLOCK];
+  double v[3] = {sp, sn, np_};
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v[q] += __shfl_down(v[q], off, 64);
+    if ((threadIdx.x & 63) == 0) red[q][threadIdx.x >> 6] = v[q];
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    double t = 0.0;
+    for (int w = 0; w < DISGAT_WAVES_PER_BLOCK; ++w) t += red[threadIdx.x][w];
+    atomicAdd(&acc[threadIdx.x], t);
+  }
+}
+
+}  // namespace disgat
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+#include "disgat_api.h"
+
+namespace disgat {
+
+template <int HL>
+static int launch_aux3(int qn, const AuxArgs& A, int grid, hipStream_t s) {
+  switch (qn) {
+    case 1: hipLaunchKernelGGL((aux_att3_kernel<HL, 1>), dim3(grid), dim3(DISGAT_BLOCK), 0, s, A); break;
+    case 2: hipLaunchKernelGGL((aux_att3_kernel<HL, 2>), dim3(grid), dim3(DISGAT_BLOCK), 0, s, A); break;
+    case 4: hipLaunchKernelGGL((aux_att3_kernel<HL, 4>), dim3(grid), dim3(DISGAT_BLOCK), 0, s, A); break;
+    case 8: hipLaunchKernelGGL((aux_att3_kernel<HL, 8>), dim3(grid), dim3(DISGAT_BLOCK), 0, s, A); break;
+    default: return fail(-2, "aux_score att=3: F_out must be QN*(64/H)*4 with QN in {1,2,4,8}");
+  }
+  return check_launch("aux_att3_kernel");
+}
+
+template <int HL>
+static int launch_aux2(int xn, const AuxArgs& A, int grid, hipStream_t s) {
+  if (xn == 1) {
+    hipLaunchKernelGGL((aux_att2_kernel<HL, 1>), dim3(grid), dim3(DISGAT_BLOCK), 0, s, A);
+  } else if (xn == 2 && HL <= 3) {
+    if constexpr (HL <= 3) hipLaunchKernelGGL((aux_att2_kernel<HL, 2>), dim3(grid), dim3(DISGAT_BLOCK), 0, s, A);
+  } else {
+    return fail(-2, "aux_score att=2: F_in=%d too wide for H=%d", A.F_in, 1 << HL);
+  }
+  return check_launch("aux_att2_kernel");
+}
+
+}  // namespace disgat
+
+extern "C" int disgat_aux_score(int att, const int64_t* pair_rows, const int64_t* pair_cols, int64_t M, int N, int H,
+                                int F_in, int F_out, int h_lo, int h_hi, const float* x, int ldx, const float* rowop,
+                                int ld_row, const float* colop, int ld_col, const float* a, float* out,
+                                disgat_stream_t stream) {
+  using namespace disgat;
+  DISGAT_REQUIRE(att >= 1 && att <= 3, "aux_score: att=%d not in 1..3", att);
+  DISGAT_REQUIRE(M >= 0 && N > 0, "aux_score: bad sizes");
+  if (M == 0 || h_lo >= h_hi) return 0;
+  const int hl = ilog2_exact(H);
+  DISGAT_REQUIRE(hl >= 1 && hl <= 4, "aux_score: H=%d must be a power of two in [2,16]", H);
+  DISGAT_REQUIRE(h_lo >= 0 && h_hi <= H, "aux_score: head range [%d,%d) outside [0,%d)", h_lo, h_hi, H);
+  DISGAT_REQUIRE(pair_rows && pair_cols && rowop && out, "aux_score: null pointer");
+  AuxArgs A{pair_rows, pair_cols, M, N, F_in, h_lo, h_hi, x, ldx, rowop, ld_row, colop, ld_col, a, out};
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int64_t waves = (M + 63) / 64;
+  const int64_t grid64 = (waves + DISGAT_WAVES_PER_BLOCK - 1) / DISGAT_WAVES_PER_BLOCK;
+  DISGAT_REQUIRE(grid64 < (int64_t)1 << 31, "aux_score: M too large for one launch");
+  const int grid = (int)grid64;
+  if (att == 1) {
+    DISGAT_REQUIRE(colop && ld_row >= H && ld_col >= H, "aux_score att=1: bad s1/s2");
+    const int g1 = (int)min((int64_t)8192, (M + 255) / 256);
+    hipLaunchKernelGGL(aux_att1_kernel, dim3(g1), dim3(256), 0, s, A);
+    return check_launch("aux_att1_kernel");
+  }
+  if (att == 2) {
+    DISGAT_REQUIRE(x && F_in > 0 && F_in % 4 == 0 && ldx % 4 == 0 && ld_row % 4 == 0 && ld_row >= H * F_in &&
+                       aligned16(x) && aligned16(rowop),
+                   "aux_score att=2: bad x/P strides or alignment");
+    const int xn = (F_in + 255) / 256;
+    switch (hl) {
+      case 1: return launch_aux2<1>(xn, A, grid, s);
+      case 2: return launch_aux2<2>(xn, A, grid, s);
+      case 3: return launch_aux2<3>(xn, A, grid, s);
+      default: return launch_aux2<4>(xn, A, grid, s);
+    }
+  }
+  const int g4 = (64 >> hl) * 4;
+  DISGAT_REQUIRE(F_out > 0 && F_out % g4 == 0, "aux_score att=3: F_out=%d must be a multiple of %d", F_out, g4);
+  DISGAT_REQUIRE(colop && a && ld_row % 4 == 0 && ld_col % 4 == 0 && ld_row >= H * F_out && ld_col >= H * F_out &&
+                     aligned16(rowop) && aligned16(colop) && aligned16(a),
+                 "aux_score att=3: bad P/Q strides or alignment");
+  const int qn = F_out / g4;
+  switch (hl) {
+    case 1: return launch_aux3<1>(qn, A, grid, s);
+    case 2: return launch_aux3<2>(qn, A, grid, s);
+    case 3: return launch_aux3<3>(qn, A, grid, s);
+    default: return launch_aux3<4>(qn, A, grid, s);
+  }
+}
+
+extern "C" int disgat_pair_loss(const float* aux, int64_t M, int h_lo, int h_hi, const float* labels, double* acc,
+                                disgat_stream_t stream) {
+  using namespace disgat;
+  DISGAT_REQUIRE(aux && labels && acc && M >= 0 && h_lo >= 0 && h_hi >= h_lo, "pair_loss: bad arguments");
+  if (M == 0) return 0;
+  const int grid = (int)min((int64_t)2048, (M + 255) / 256);
+  hipLaunchKernelGGL(pair_loss_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), aux, M, h_lo,
+                     h_hi, labels, acc);
+  return check_launch("pair_loss_kernel");
+}

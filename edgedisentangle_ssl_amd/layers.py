@@ -1,0 +1,266 @@
+"""Host-side mirror of the reference's layer classes on the DISGAT path.
+
+Same class names, constructor signatures, parameter names (= state_dict keys)
+and initialisers as /root/reference/layers.py, so checkpoints and seeds carry
+over; the sparse forward of all heads of a layer is ONE fused HIP edge pass
+(csrc/edge_fwd.hip) plus dense GEMMs, instead of H sequential ATen pipelines.
+
+  DisGALayer        layers.py:303-511   (one attention head; parameters only + single-head forward)
+  SageConv          layers.py:63-112    (parameter container; math fused in disga_heads)
+  GraphConvolution  layers.py:16-59     (parameter container; math fused in disga_heads)
+  FuseLayer         layers.py:876-921
+  disga_heads()     the H-head loop of models.py:225-228 / 240-243 as one call
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .graph import CSRGraph, graph_of
+
+
+def _pow2ceil(v):
+    p = 1
+    while p < v:
+        p *= 2
+    return p
+
+
+class GraphConvolution(nn.Module):
+    """Parameters of the reference GCN layer (layers.py:16-36): weight [F_in,F_out], bias [F_out],
+    uniform(+-1/sqrt(F_out))."""
+
+    def __init__(self, in_features, out_features, bias=True):
+        super().__init__()
+        self.in_features = in_features
+        self.out_features = out_features
+        self.weight = nn.Parameter(torch.FloatTensor(in_features, out_features))
+        if bias:
+            self.bias = nn.Parameter(torch.FloatTensor(out_features))
+        else:
+            self.register_parameter("bias", None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        stdv = 1.0 / math.sqrt(self.weight.size(1))
+        self.weight.data.uniform_(-stdv, stdv)
+        if self.bias is not None:
+            self.bias.data.uniform_(-stdv, stdv)
+
+
+class SageConv(nn.Module):
+    """Parameters of the reference GraphSage layer (layers.py:63-82): proj = Linear(2*F_in -> F_out,
+    bias=False) with N(0,1) weights."""
+
+    def __init__(self, in_features, out_features, bias=False):
+        super().__init__()
+        self.proj = nn.Linear(in_features * 2, out_features, bias=bias)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        nn.init.normal_(self.proj.weight)
+        if self.proj.bias is not None:
+            nn.init.constant_(self.proj.bias, 0.0)
+
+
+class DisGALayer(nn.Module):
+    """One edge-disentangled attention head (layers.py:303-337 for the parameters).
+
+    forward(input, adj, aux_indices=None) keeps the reference's single-head contract
+    (layers.py:493-511): returns (elu(h'), edge_e[E,1]) or (elu(h'), edge_e, [aux_e[M,1]...]).
+    DISGAT does not call it per head; it hands all heads of a layer to disga_heads().
+    """
+
+    def __init__(self, in_features, out_features, dropout, alpha, concat=True, att_type=1, gnn_type="AT"):
+        super().__init__()
+        self.dropout = dropout
+        self.in_features = in_features
+        self.out_features = out_features
+        self.alpha = alpha            # unused by the reference as well (no LeakyReLU(alpha) on att 1)
+        self.concat = concat
+        self.att_type = att_type
+        self.gnn_type = gnn_type
+        if att_type == 3:
+            self.W = nn.Parameter(torch.zeros(size=(in_features * 2, out_features)))
+            nn.init.xavier_uniform_(self.W.data, gain=1.414)
+            self.a = nn.Parameter(torch.zeros(size=(out_features, 1)))
+            nn.init.xavier_uniform_(self.a.data, gain=1.414)
+        else:
+            self.W = nn.Parameter(torch.zeros(size=(in_features, out_features)))
+            nn.init.xavier_uniform_(self.W.data, gain=1.414)
+            self.a = nn.Parameter(torch.zeros(size=(2 * out_features, 1)))
+            nn.init.xavier_uniform_(self.a.data, gain=1.414)
+        if gnn_type == "AT":
+            self.W_em = nn.Parameter(torch.zeros(size=(in_features, out_features)))
+            nn.init.xavier_uniform_(self.W_em.data, gain=1.414)
+        elif gnn_type == "SAGE":
+            self.ag_layer = SageConv(in_features, out_features)
+        elif gnn_type == "GCN":
+            self.ag_layer = GraphConvolution(in_features, out_features)
+        else:
+            raise ValueError("not implemented for gnn_type {} in DISGAT".format(gnn_type))   # layers.py:409
+
+    def forward(self, input, adj, aux_indices=None):
+        heads, edge_e, aux = disga_heads([self], input, adj, aux_indices)
+        out = heads[0] if self.concat else heads.pre_elu[0]
+        if aux_indices is not None:
+            if self.concat:
+                return out, edge_e[0], aux[0]
+            return out, edge_e[0]                      # layers.py:501-502 drops the aux scores
+        return out, edge_e[0]
+
+
+class HeadList(list):
+    """List of the H per-head outputs [N,F_out] (what the reference's fusers receive,
+    models.py:230-233).  All heads are column slices of ONE buffer `fused` [N, H*F_out], which a
+    fuser may use directly instead of re-concatenating (FuseLayer below does)."""
+    fused = None
+    pre_elu = None
+
+
+def _pack_score_operands(layers, x, att, H, Hp, f_in, f_out):
+    """Dense, differentiable (torch ops -> MFMA GEMMs) preparation of the per-node score operands.
+
+    att 1 (layers.py:349-353):  e = [h_r || h_c] . a,  h = x W   ==  s1[r] + s2[c]
+                                with s1 = x (W a[:F]),  s2 = x (W a[F:])           -> [N,Hp] each
+    att 2 (layers.py:362-365):  e = <x_r W, x_c W> = <x_r (W W^T), x_c>           -> P = x (W W^T)
+    att 3 (layers.py:374-379):  e = a . lrelu([x_r || x_c] W) = a . lrelu(P[r] + Q[c]),
+                                P = x W[:F_in], Q = x W[F_in:]                     -> [N,Hp*F_out_p] each
+    Returns (rowop, colop, a_vec, F_out_padded).
+    """
+    if att == 1:
+        cols1 = [l.W @ l.a[:f_out, 0] for l in layers]
+        cols2 = [l.W @ l.a[f_out:, 0] for l in layers]
+        zero = [x.new_zeros(f_in)] * (Hp - H)
+        wc = torch.stack(cols1 + zero + cols2 + zero, dim=1)            # [F_in, 2*Hp]
+        s = x @ wc
+        return s[:, :Hp], s[:, Hp:], None, f_out
+    if att == 2:
+        f_in_p = (f_in + 3) // 4 * 4
+        ms = [F.pad(l.W @ l.W.t(), (0, f_in_p - f_in)) for l in layers]
+        ms += [x.new_zeros(f_in, f_in_p)] * (Hp - H)
+        p = x @ torch.cat(ms, dim=1)                                    # [N, Hp*F_in_p]
+        return p, None, None, f_out
+    g4 = (64 // Hp) * 4
+    qn = _pow2ceil((f_out + g4 - 1) // g4)
+    if qn > 8:
+        raise NotImplementedError(
+            f"att=3 kernel envelope: nhead*nhid must be <= 2048 after padding (got H={Hp}, F_out={f_out})")
+    fp = qn * g4
+    tops = [F.pad(l.W[:f_in], (0, fp - f_out)) for l in layers] + [x.new_zeros(f_in, fp)] * (Hp - H)
+    bots = [F.pad(l.W[f_in:], (0, fp - f_out)) for l in layers] + [x.new_zeros(f_in, fp)] * (Hp - H)
+    pq = x @ torch.cat(tops + bots, dim=1)                              # [N, 2*Hp*fp]
+    hf = Hp * fp
+    a_vec = torch.cat([F.pad(l.a[:, 0], (0, fp - f_out)) for l in layers] + [x.new_zeros(fp)] * (Hp - H))
+    return pq[:, :hf], pq[:, hf:], a_vec.contiguous(), fp
+
+
+def disga_heads(layers, x, adj, aux_indices=None, head_ranges=None):
+    """All H heads of one DISGAT layer: the loop of models.py:225-228 as ONE fused edge pass.
+
+    layers: the H DisGALayer modules (parameter holders).  adj: torch sparse COO or CSRGraph.
+    aux_indices: optional list of int64 (2,M_l) pair lists (layers.py:341).  head_ranges:
+    optional list of (lo,hi) per aux list restricting which heads are scored on it (DisEdge uses
+    half the heads per list, pretrainer.py:619-620); unscored heads' entries are None.
+    Returns (HeadList of elu(h') [N,F_out], [edge_e[E,1]]*H, [[aux_e[M_l,1]]_l]*H or None).
+    """
+    l0 = layers[0]
+    att, gnn = l0.att_type, l0.gnn_type
+    H = len(layers)
+    f_in, f_out = l0.in_features, l0.out_features
+    if x.dim() != 2 or x.shape[1] != f_in:
+        raise ValueError(f"expected a 2-D [N,{f_in}] input (layers.py:475 asserts 2-D), got {tuple(x.shape)}")
+    if not x.is_cuda:
+        raise RuntimeError("DISGAT HIP path: input must live on the GPU; there is no CPU fallback")
+    if l0.training and l0.dropout > 0:
+        # attention dropout (layers.py:394) is not fused yet: refuse rather than silently skip it
+        raise NotImplementedError("attention dropout > 0 in training mode is not built yet; use --dropout 0 or eval()")
+    graph = graph_of(adj)
+    if graph.n != x.shape[0]:
+        raise ValueError("adjacency / feature row count mismatch")
+    Hp = max(2, _pow2ceil(H))
+    if Hp > 16:
+        raise NotImplementedError("more than 16 heads is outside the kernel envelope")
+    f_in_p = (f_in + 3) // 4 * 4
+    if f_in_p > 512 or Hp * ((f_in_p + 255) // 256) > 16:
+        raise NotImplementedError(f"kernel envelope: F_in={f_in} with {Hp} heads does not fit the register tile")
+    xg = x if (f_in_p == f_in and x.is_contiguous()) else F.pad(x, (0, f_in_p - f_in)).contiguous()
+
+    rowop, colop, a_vec, f_out_p = _pack_score_operands(layers, x, att, H, Hp, f_in, f_out)
+    cfg = (graph, att, Hp, f_in_p, f_out_p, gnn == "SAGE")
+    z, edge_e, _den = ops.EdgePass.apply(xg, rowop, colop, a_vec, cfg)
+
+    # ---- per-head output projection on the aggregated neighbourhood (dense, MFMA)
+    zt = z[:, :H, :f_in].permute(1, 0, 2)                               # [H,N,F_in] strided view
+    if gnn == "AT":                                                      # layers.py:397-399
+        w = torch.stack([l.W_em for l in layers])                        # [H,F_in,F_out]
+        h3 = torch.bmm(zt, w)
+    elif gnn == "SAGE":                                                  # layers.py:96-110
+        wx = torch.cat([l.ag_layer.proj.weight[:, :f_in].t() for l in layers], dim=1)   # [F_in, H*F_out]
+        wn = torch.stack([l.ag_layer.proj.weight[:, f_in:].t() for l in layers])        # [H,F_in,F_out]
+        hx = (x @ wx).view(-1, H, f_out).permute(1, 0, 2)
+        h3 = torch.baddbmm(hx, zt, wn)
+    else:                                                                # layers.py:38-54
+        w = torch.stack([l.ag_layer.weight for l in layers])
+        b = torch.stack([l.ag_layer.bias for l in layers]).unsqueeze(1)  # [H,1,F_out]
+        h3 = torch.baddbmm(b, zt, w)
+    heads = HeadList(F.elu(h3).unbind(0))                                # layers.py:508-509
+    heads.pre_elu = h3.unbind(0)
+
+    e_list = [edge_e[h].unsqueeze(1) for h in range(H)]
+
+    aux_out = None
+    if aux_indices is not None:
+        if not isinstance(aux_indices, list):
+            aux_indices = [aux_indices]
+        per_list = []
+        for li, pairs in enumerate(aux_indices):
+            lo, hi = (0, H) if head_ranges is None or head_ranges[li] is None else head_ranges[li]
+            acfg = (att, Hp, f_in_p, f_out_p, graph.n, lo, hi)
+            out = ops.AuxPass.apply(xg if att == 2 else None, rowop, colop, a_vec, pairs, acfg)
+            per_list.append([out[h].unsqueeze(1) if lo <= h < hi else None for h in range(H)])
+        aux_out = [[per_list[li][h] for li in range(len(aux_indices))] for h in range(H)]
+    return heads, e_list, aux_out
+
+
+class FuseLayer(nn.Module):
+    """layers.py:876-921: cat heads (+residue) -> Linear -> leaky_relu, three residue_type variants."""
+
+    def __init__(self, args, nheads, nfeat=64, residue=0):
+        super().__init__()
+        self.args = args
+        self.nheads = nheads
+        self.nfeat = nfeat
+        self.residue_dim = residue
+        if self.args.residue_type == 0:
+            self.fuse = nn.Linear(self.nfeat * nheads + self.residue_dim, self.nfeat)
+        if self.args.residue_type == 1:
+            self.fuse = nn.Linear(self.nfeat * nheads + self.residue_dim, self.nfeat * 2)
+            self.fuse2 = nn.Linear(self.nfeat * 2, self.nfeat)
+        if self.args.residue_type == 2:
+            self.fuse = nn.Linear(self.nfeat * nheads, self.nfeat)
+            if self.residue_dim != 0:
+                self.fuse2 = nn.Linear(self.residue_dim, self.nfeat)
+
+    def forward(self, feature_list, residue=None):
+        features = getattr(feature_list, "fused", None)
+        if features is None:
+            features = torch.cat(list(feature_list), dim=-1)
+        use_res = self.residue_dim != 0 and residue is not None
+        if self.args.residue_type == 0:
+            if use_res:
+                features = torch.cat([features, residue], dim=-1)
+            feature = self.fuse(features)
+        elif self.args.residue_type == 1:
+            if use_res:
+                features = torch.cat([features, residue], dim=-1)
+            feature = self.fuse2(F.leaky_relu(self.fuse(features)))
+        else:
+            feature = self.fuse(features)
+            if use_res:
+                feature = feature + self.fuse2(residue)
+        if not self.args.fuse_no_relu:
+            feature = F.leaky_relu(feature)
+        return feature

@@ -1,0 +1,90 @@
+"""DISGAT encoder and MLP head: drop-in mirrors of /root/reference/models.py:151-373 and :523-543.
+
+Same constructor and method signatures, same registered sub-module names
+(`attention1_i`, `attention2_i`, `fuser1`, `fuser2` -> identical state_dict keys,
+models.py:165-179), same return conventions.  The H per-head DisGALayer calls of
+each layer run as one fused HIP edge pass (layers.disga_heads).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .layers import DisGALayer, FuseLayer, disga_heads
+
+
+class DISGAT(nn.Module):
+    def __init__(self, args, nfeat, nhid, nclass, dropout, is_specific=[True, True], alpha=0.1, nheads=4):
+        super().__init__()
+        self.dropout = dropout
+        self.args = args
+        self.nheads = nheads
+        self.gnn_type = args.gnn_type
+        self.is_specific = is_specific
+        self.attentions1 = [DisGALayer(nfeat, nhid, dropout=dropout, alpha=alpha, concat=True, att_type=args.att,
+                                       gnn_type=self.gnn_type) for _ in range(nheads)]
+        for i, attention in enumerate(self.attentions1):
+            self.add_module("attention1_{}".format(i), attention)
+        self.attentions2 = [DisGALayer(nhid, nclass, dropout=dropout, alpha=alpha, concat=True, att_type=args.att,
+                                       gnn_type=self.gnn_type) for _ in range(nheads)]
+        for i, attention in enumerate(self.attentions2):
+            self.add_module("attention2_{}".format(i), attention)
+        if args.residue:
+            self.fuser1 = FuseLayer(args, nheads, nfeat=nhid, residue=nfeat)
+            self.fuser2 = FuseLayer(args, nheads, nfeat=nhid, residue=nhid)
+        else:
+            self.fuser1 = FuseLayer(args, nheads, nfeat=nhid)
+            self.fuser2 = FuseLayer(args, nheads, nfeat=nhid)
+
+    # The five entry points of the reference share one two-layer loop (models.py:181-373);
+    # `_run` is that loop, returning everything any of them needs.
+    def _run(self, x, adj, fusers, auxiliary_edges=None, head_ranges=None):
+        if not isinstance(fusers, list):
+            fusers = [fusers]
+        x = F.dropout(x, self.dropout, training=self.training)
+        h1, adj1, aux1 = disga_heads(self.attentions1, x, adj, auxiliary_edges, head_ranges)
+        f1 = self.fuser1(h1, x) if not self.is_specific[0] else fusers[0](h1, x)
+        feature_1 = F.dropout(f1, self.dropout, training=self.training)
+        h2, adj2, aux2 = disga_heads(self.attentions2, feature_1, adj, auxiliary_edges, head_ranges)
+        f2 = self.fuser2(h2, feature_1) if not self.is_specific[1] else fusers[1](h2, feature_1)
+        return dict(x=x, feature_1=feature_1, x2=f2, heads=(h1, h2), adjs=(adj1, adj2), aux=(aux1, aux2))
+
+    def forward(self, x, adj, fusers):                                   # models.py:181-214
+        return F.log_softmax(self._run(x, adj, fusers)["x2"], dim=1)
+
+    def get_em(self, x, adj, fusers):                                    # models.py:217-252
+        r = self._run(x, adj, fusers)
+        feature_2 = F.dropout(r["x2"], self.dropout, training=self.training)
+        return [r["feature_1"], feature_2]
+
+    def get_adjs(self, x, adj, fusers):                                  # models.py:254-288
+        r = self._run(x, adj, fusers)
+        return [r["adjs"][0], r["adjs"][1]]
+
+    def predict_adjs_sparse(self, x, adj, fusers, auxiliary_edges, head_ranges=None):   # models.py:290-330
+        r = self._run(x, adj, fusers, auxiliary_edges, head_ranges)
+        return [r["aux"][0], r["aux"][1]]
+
+    def get_edge_em(self, x, adj, fusers):                               # models.py:333-373
+        r = self._run(x, adj, fusers)
+        e1 = [torch.cat((r["x"], h), dim=-1) for h in r["heads"][0]]
+        e2 = [torch.cat((r["feature_1"], h), dim=-1) for h in r["heads"][1]]
+        return [e1, e2]
+
+
+class MLP(nn.Module):
+    """models.py:523-543: Linear -> LeakyReLU(0.1) -> ... -> Linear (+ log_softmax when cls)."""
+
+    def __init__(self, in_feat, hidden_size, out_size, layers=2, dropout=0.1):
+        super().__init__()
+        modules = []
+        in_size = in_feat
+        for _ in range(layers - 1):
+            modules.append(nn.Linear(in_size, hidden_size))
+            in_size = hidden_size
+            modules.append(nn.LeakyReLU(0.1))
+        modules.append(nn.Linear(in_size, out_size))
+        self.model = nn.Sequential(*modules)
+
+    def forward(self, features, cls=False):
+        output = self.model(features)
+        return F.log_softmax(output, dim=1) if cls else output

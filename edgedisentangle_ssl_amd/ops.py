@@ -1,0 +1,123 @@
+"""torch.autograd.Function wrappers around the C ABI (include/disgat_hip.h).
+
+PyTorch is plumbing here: it owns the device buffers and the stream; the
+launchers borrow raw pointers for the duration of a launch.  Every op requires
+CUDA (ROCm) tensors and the in-tree libdisgat_hip.so - there is no fallback.
+"""
+import torch
+
+from . import _lib
+from .graph import CSRGraph
+
+# max edges per work item, by attention type: bounds the tail on power-law rows while keeping
+# the partial-record traffic (H*F_in floats per chunk) small next to the chunk's gather bytes.
+CHUNK = {1: 256, 2: 256, 3: 128}
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _check(t, name, dtype=torch.float32):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: the DISGAT HIP path needs device tensors (got {t.device}); no CPU fallback exists")
+    if t.dtype != dtype:
+        raise RuntimeError(f"{name}: expected {dtype}, got {t.dtype}")
+
+
+def _row_major(t, name):
+    if t.stride(-1) != 1:
+        raise RuntimeError(f"{name}: innermost stride must be 1")
+    return t
+
+
+def edge_forward(graph: CSRGraph, att, H, F_in, F_out, x, rowop, colop, a, sage_div, need_den=True):
+    """Launch disgat_edge_fwd (+ disgat_edge_combine for split rows).
+
+    x [N, >=F_in] (row stride % 4 == 0), rowop/colop 2-D views with unit inner
+    stride, a [H*F_out] or None.  Returns Z [N,H,F_in], edge_e [H,E], den [N,H].
+    """
+    for t, nm in ((x, "x"), (rowop, "rowop")) + (((colop, "colop"),) if colop is not None else ()):
+        _check(t, nm)
+        _row_major(t, nm)
+    n, e = graph.n, graph.nnz
+    dev = x.device
+    wi = graph.work_items(CHUNK[att])
+    z = torch.empty((n, H, F_in), dtype=torch.float32, device=dev)
+    edge_e = torch.empty((H, e), dtype=torch.float32, device=dev)
+    den = torch.empty((n, H), dtype=torch.float32, device=dev) if need_den else None
+    part_z = part_den = None
+    if wi.n_slots:
+        part_z = torch.empty((wi.n_slots, H, F_in), dtype=torch.float32, device=dev)
+        part_den = torch.empty((wi.n_slots, H), dtype=torch.float32, device=dev)
+    st = _stream()
+    _lib.call("disgat_edge_fwd", att, _ptr(wi.items), wi.n_items, _ptr(graph.col), e, n, H, F_in, F_out,
+              _ptr(x), x.stride(0), _ptr(rowop), rowop.stride(0), _ptr(colop), 0 if colop is None else colop.stride(0),
+              _ptr(a), _ptr(z), _ptr(edge_e), _ptr(den), _ptr(part_z), _ptr(part_den), int(bool(sage_div)), st)
+    if wi.n_split:
+        _lib.call("disgat_edge_combine", _ptr(wi.split_rows), _ptr(wi.split_ptr), wi.n_split, H, F_in,
+                  _ptr(part_z), _ptr(part_den), _ptr(z), _ptr(den), int(bool(sage_div)), st)
+    return z, edge_e, den
+
+
+def aux_forward(att, H, F_in, F_out, pairs, n, x, rowop, colop, a, h_lo=0, h_hi=None):
+    """Launch disgat_aux_score.  pairs: int64 [2,M] device tensor.  Returns [H,M]
+    (rows outside [h_lo,h_hi) are left uninitialised and must not be read)."""
+    if pairs.dtype != torch.int64 or not pairs.is_cuda:
+        raise RuntimeError("auxiliary pair list must be an int64 device tensor of shape (2,M)")
+    h_hi = H if h_hi is None else h_hi
+    pairs = pairs.contiguous()
+    m = int(pairs.shape[1])
+    out = torch.empty((H, m), dtype=torch.float32, device=pairs.device)
+    _lib.call("disgat_aux_score", att, pairs[0].data_ptr(), pairs[1].data_ptr(), m, n, H, F_in, F_out, h_lo, h_hi,
+              _ptr(x), 0 if x is None else x.stride(0), _ptr(rowop), rowop.stride(0),
+              _ptr(colop), 0 if colop is None else colop.stride(0), _ptr(a), _ptr(out), _stream())
+    return out
+
+
+def pair_loss_sums(aux, h_lo, h_hi, labels):
+    """disgat_pair_loss: returns a float64 device tensor [sum_sq_pos, sum_sq_neg, n_pos]."""
+    _check(aux, "aux")
+    _check(labels, "labels")
+    acc = torch.zeros(3, dtype=torch.float64, device=aux.device)
+    if aux.stride(1) != 1 or aux.stride(0) != aux.shape[1]:
+        raise RuntimeError("aux must be a contiguous [H,M] tensor")
+    _lib.call("disgat_pair_loss", _ptr(aux), int(aux.shape[1]), h_lo, h_hi, _ptr(labels.contiguous()), _ptr(acc), _stream())
+    return acc
+
+
+class EdgePass(torch.autograd.Function):
+    """Differentiable wrapper of edge_forward.  Non-tensor config travels in `cfg`."""
+
+    @staticmethod
+    def forward(ctx, x, rowop, colop, a, cfg):
+        graph, att, H, F_in, F_out, sage = cfg
+        z, edge_e, den = edge_forward(graph, att, H, F_in, F_out, x, rowop, colop, a, sage)
+        ctx.cfg = cfg
+        ctx.save_for_backward(x, rowop, colop, a, z, edge_e, den)
+        ctx.mark_non_differentiable(den)
+        return z, edge_e, den
+
+    @staticmethod
+    def backward(ctx, gz, ge, _gden):
+        from . import ops_bwd
+        return ops_bwd.edge_backward(ctx, gz, ge)
+
+
+class AuxPass(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, rowop, colop, a, pairs, cfg):
+        att, H, F_in, F_out, n, h_lo, h_hi = cfg
+        out = aux_forward(att, H, F_in, F_out, pairs, n, x, rowop, colop, a, h_lo, h_hi)
+        ctx.cfg = cfg
+        ctx.save_for_backward(x, rowop, colop, a, pairs)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        from . import ops_bwd
+        return ops_bwd.aux_backward(ctx, gout)
