@@ -1,0 +1,260 @@
+#!/usr/bin/env python3
+"""DISGAT forward + SSL-loss throughput on MI355X (BASELINE.json metric).
+
+One "step" = T_iter of SURVEY 8(d): the forward of the three self-supervised passes exactly as
+the reference sequences them - [SupEdge: predict_adjs_sparse + loss] + [DisEdge: predict_adjs_sparse
+on the homo / hetero lists + loss] + [DifHead: get_edge_em + MLP + NLL] - each with its own fusers,
+dropout 0, pre-sampled pair lists resident in HBM, CSR preprocessing outside the timed region.
+value = E_nnz (summed over ranks) / time per step.
+
+  python bench.py [--gpus N --steps K --warmup W]          (N>1: launched by torch.distributed.run)
+
+N = 1 workload: BASELINE configs[3]'s graph on one GPU (the size north_star's single-GPU target is
+quoted on): synthetic power-law, 1M nodes / 20M edges, 256-dim, 8 heads, att 3, gnn_type AT.
+N > 1: weak scaling - every rank owns 1M rows / ~20M entries of an N-times larger graph (N = 8 is
+configs[4]'s 8M nodes / 160M edges), one all-gather of the layer input per layer over RCCL.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--nodes", type=int, default=1_000_000)
+    ap.add_argument("--edges", type=int, default=20_000_000)
+    ap.add_argument("--feat", type=int, default=256)
+    ap.add_argument("--heads", type=int, default=8)
+    ap.add_argument("--att", type=int, default=3)
+    ap.add_argument("--gnn_type", default="AT")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-nodes", type=int, default=8192)
+    ap.add_argument("--fwd-only", action="store_true", help="time one get_em (T_fwd) instead of T_iter")
+    return ap.parse_args()
+
+
+def make_args(o):
+    return SimpleNamespace(gnn_type=o.gnn_type, att=o.att, nhead=o.heads, nhid=o.feat, size=o.feat, residue=False,
+                           residue_type=0, fuse_no_relu=False, dropout=0.0, cls_layer=2, constrain_layer=0,
+                           sparse=True, model="DISGAT", dis_type=1, lr=0.01, weight_decay=5e-4)
+
+
+def sharded_graph(o, rank, world, dev):
+    """Rows of this rank in a world-times larger power-law graph (local generation, no exchange):
+    the symmetrised generator of SURVEY 8(d) gives row i its own power-law out-entries (uniform
+    columns) plus Poisson many in-entries (power-law columns); both are drawn here per rank."""
+    from edgedisentangle_ssl_amd.parallel import DistGraph
+    n_loc, n_glob = o.nodes, o.nodes * world
+    rng = np.random.Generator(np.random.PCG64([1234, rank]))
+    m = (o.edges - n_loc) // 2
+    w = (np.arange(n_loc, dtype=np.float64) + 1.0) ** -0.8
+    w /= w.sum()
+    perm = rng.permutation(n_loc)
+    r_out = perm[rng.choice(n_loc, m, p=w)]
+    c_out = rng.integers(0, n_glob, m)
+    r_in = rng.integers(0, n_loc, m)
+    c_in = rng.integers(0, world, m) * n_loc + perm[rng.choice(n_loc, m, p=w)]
+    loop = np.arange(n_loc)
+    rows = torch.from_numpy(np.concatenate([r_out, r_in, loop])).to(dev)
+    cols = torch.from_numpy(np.concatenate([c_out, c_in, loop + rank * n_loc])).to(dev)
+    return DistGraph.from_local_edges(rows, cols, n_loc, n_glob, rank * n_loc, [n_loc] * world)
+
+
+def build_workload(o, rank, world, dev):
+    from edgedisentangle_ssl_amd import DISGAT, pretrainer, sampling, synth
+    a = make_args(o)
+    torch.manual_seed(0)                      # reference initialisers under a fixed seed
+    enc = DISGAT(a, nfeat=o.feat, nhid=o.feat, nclass=o.feat, nheads=o.heads, dropout=0.0).to(dev).eval()
+    sup = pretrainer.SupEdgeTrainer(a, enc, 1.0)
+    dis = pretrainer.GeneratedEdgeTrainer(a, enc, 1.0)
+    dif = pretrainer.DifHeadTrainer(a, enc, 1.0)
+    for tr in (sup, dis, dif):
+        for m in tr.models:
+            m.eval()
+    if world == 1:
+        graph = synth.powerlaw_graph(o.nodes, o.edges, dev)
+        labels = synth.node_labels(o.nodes, dev)
+        lists = synth.ssl_lists(graph, labels)
+    else:
+        graph = sharded_graph(o, rank, world, dev)
+        n_glob = graph.n_global
+        labels_all = synth.node_labels(n_glob, dev)
+        same = labels_all[graph.row + graph.row_start] == labels_all[graph.col.long()]
+        pos = graph.row * n_glob + graph.col.long()
+        m_sup = (10 * graph.nnz) // 3
+        rng = np.random.Generator(np.random.PCG64([99, rank]))
+
+        def pairs(m, posset):
+            flat = torch.sort(torch.from_numpy(rng.integers(0, graph.n * n_glob, m)).to(dev)).values
+            rows = torch.div(flat, n_glob, rounding_mode="floor")
+            return torch.stack([rows, flat - rows * n_glob]), sampling.membership(flat, posset)
+        lists = (pairs(m_sup, pos), pairs(m_sup // 4, pos[same]), pairs(m_sup - m_sup // 4, pos[~same]))
+    x = synth.features(o.nodes, o.feat, dev, seed=rank)
+    graph.work_items(__import__("edgedisentangle_ssl_amd").ops.CHUNK[o.att])   # CSR preprocessing: untimed
+    return a, enc, (sup, dis, dif), graph, x, lists
+
+
+def one_step(o, enc, trainers, graph, x, lists):
+    sup, dis, dif = trainers
+    data = (x, graph)
+    with torch.no_grad():
+        if o.fwd_only:
+            return enc.get_em(x, graph, [sup.fuse1, sup.fuse2])[1].sum()
+        (si, sl), (hi, hl), (ti, tl) = lists
+        l1 = sup.loss(data, sl, [si])
+        l2 = dis.loss(data, [hl, tl], [hi, ti])
+        l3 = dif.loss(data)
+        return l1 + l2 + l3
+
+
+def cpu_baseline(o):
+    """The oracle (CPU restatement of the reference's op sequence: kind "port") timed on this box's
+    host cores on a bounded sample of the same workload: same generator, feature width, heads and
+    attention type, fewer nodes (about 10-30 s of CPU work)."""
+    from oracle import disgat_oracle as orc
+    from edgedisentangle_ssl_amd import DISGAT, MLP, FuseLayer, sampling, synth
+    torch.set_num_threads(os.cpu_count() or 1)
+    n = o.cpu_nodes
+    e = n * (o.edges // o.nodes)
+    cpu = torch.device("cpu")
+    graph = synth.powerlaw_graph(n, e, cpu)
+    labels = synth.node_labels(n, cpu)
+    (si, sl), (hi, hl), (ti, tl) = synth.ssl_lists(graph, labels)
+    x = synth.features(n, o.feat, cpu)
+    a = make_args(o)
+    torch.manual_seed(0)
+    enc = DISGAT(a, nfeat=o.feat, nhid=o.feat, nclass=o.feat, nheads=o.heads, dropout=0.0)
+    sd = {k: v.detach() for k, v in enc.state_dict().items()}
+    fus = []
+    for _ in range(3):
+        pair = [FuseLayer(a, o.heads, nfeat=o.feat), FuseLayer(a, o.heads, nfeat=o.feat)]
+        fus.append([(lambda hs, r, p={k: v.detach() for k, v in f.state_dict().items()}: orc.fuse_layer(p, hs, r)) for f in pair])
+    c1 = {k: v.detach() for k, v in MLP(o.feat * 2, o.feat, o.heads).state_dict().items()}
+    c2 = {k: v.detach() for k, v in MLP(o.feat * 2, o.feat, o.heads).state_dict().items()}
+    ei = graph.indices()
+
+    def step():
+        with torch.no_grad():
+            r = orc.disgat_pass(sd, x, ei, fus[0], o.heads, o.att, o.gnn_type, [si])
+            l1 = orc.sup_edge_loss(r["aux"], sl)
+            r = orc.disgat_pass(sd, x, ei, fus[1], o.heads, o.att, o.gnn_type, [hi, ti])
+            l2 = orc.dis_edge_loss(r["aux"], hl, tl)
+            r = orc.disgat_pass(sd, x, ei, fus[2], o.heads, o.att, o.gnn_type)
+            l3 = orc.dif_head_loss(r["edge_em"], c1, c2)
+        return float(l1 + l2 + l3)
+
+    t0 = time.time()
+    step()
+    t1 = time.time() - t0
+    reps = 1 if t1 > 12 else 2
+    t0 = time.time()
+    for _ in range(reps):
+        step()
+    dt = (time.time() - t0) / reps
+    return {"value": graph.nnz / dt, "unit": "edges/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"same generator/config, N={n} nnz={graph.nnz} F={o.feat} H={o.heads} att={o.att} "
+                      f"gnn={o.gnn_type}, T_iter {dt:.2f}s, best-effort {reps} run(s) after 1 warm-up"}
+
+
+def main():
+    o = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != o.gpus and world > 1:
+        raise SystemExit(f"--gpus {o.gpus} but WORLD_SIZE={world}")
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    from edgedisentangle_ssl_amd import _lib, ops
+    _lib.load()
+    a, enc, trainers, graph, x, lists = build_workload(o, rank, world, dev)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(o.warmup):
+        one_step(o, enc, trainers, graph, x, lists)
+    sync()
+    ops.PROFILE = []
+    t0 = time.perf_counter()
+    for _ in range(o.steps):
+        last = one_step(o, enc, trainers, graph, x, lists)
+    sync()
+    dt = time.perf_counter() - t0
+    prof, ops.PROFILE = ops.PROFILE, None
+    t = torch.tensor([dt, float(graph.nnz)], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        dt, nnz_total = float(tmax[0]), float(t[1])
+    else:
+        nnz_total = float(graph.nnz)
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    assert torch.isfinite(last).all(), "non-finite loss in the timed region"
+
+    # dominant hot-path kernel: algorithmic bytes / HIP-event duration of its launches
+    agg = {}
+    for label, nbytes, s, e in prof:
+        d = agg.setdefault(label, [0.0, 0.0, 0])
+        d[0] += nbytes
+        d[1] += s.elapsed_time(e) * 1e-3
+        d[2] += 1
+    roof = None
+    if agg:
+        label, (b, sec, cnt) = max(agg.items(), key=lambda kv: kv[1][1])
+        ach = b / sec / 1e9
+        roof = {"bound": "hbm", "kernel": label, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "launches": cnt,
+                "avg_launch_ms": round(sec / cnt * 1e3, 3), "algorithmic_bytes_per_launch": int(b / cnt),
+                "all_kernels": {k: {"GB/s": round(v[0] / v[1] / 1e9, 1), "ms_total": round(v[1] * 1e3, 2), "launches": v[2]}
+                                for k, v in agg.items()}}
+    cpu = None
+    if not o.no_cpu_baseline:
+        cpu = cpu_baseline(o)
+    ms = dt / o.steps * 1e3
+    what = "T_fwd(get_em)" if o.fwd_only else "T_iter(SupEdge+DisEdge+DifHead fwd+loss)"
+    out = {
+        "metric": "DISGAT fwd+SSL-loss edges/sec", "value": nnz_total / (dt / o.steps), "unit": "edges/s",
+        "n_gpus": world, "steps": o.steps, "warmup": o.warmup, "ms_per_step": ms, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"synthetic power-law {o.nodes} nodes/rank, nnz {int(nnz_total)} total, F={o.feat}, "
+                               f"H={o.heads}, att={o.att}, gnn_type={o.gnn_type}; {what}; "
+                               + ("BASELINE configs[3] graph on 1 GPU" if world == 1 else f"row-sharded over {world} GPUs"),
+                   "nodes_per_rank": o.nodes, "nnz_total": int(nnz_total), "feat": o.feat, "heads": o.heads,
+                   "att": o.att, "gnn_type": o.gnn_type, "parallelism": f"row-range x{world}"},
+        "roofline": roof, "cpu_baseline": cpu,
+    }
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -77,16 +77,6 @@ _SIGS = {
     "disgat_aux_score": (_c.c_int, [_c.c_int, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
                                     _c.c_int, _P, _c.c_int, _P, _c.c_int, _P, _c.c_int, _P, _P, _P]),
     "disgat_pair_loss": (_c.c_int, [_P, _c.c_int64, _c.c_int, _c.c_int, _P, _P, _P]),
-    "disgat_edge_bwd": (_c.c_int, [_c.c_int, _P, _c.c_int, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
-                                   _P, _c.c_int, _P, _c.c_int, _P, _c.c_int, _P,
-                                   _P, _P, _P, _P, _P,
-                                   _P, _P, _P, _P, _P, _c.c_int, _P]),
-    "disgat_edge_bwd_col": (_c.c_int, [_c.c_int, _P, _P, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
-                                       _P, _c.c_int, _P, _c.c_int, _P, _c.c_int, _P,
-                                       _P, _P, _P, _P, _P, _c.c_int, _P]),
-    "disgat_aux_bwd": (_c.c_int, [_c.c_int, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
-                                  _c.c_int, _P, _c.c_int, _P, _c.c_int, _P, _c.c_int, _P, _P,
-                                  _P, _P, _P, _P, _P]),
 }
 
 

@@ -17,7 +17,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops
+from . import ops, parallel
 from .graph import CSRGraph, graph_of
 
 
@@ -120,8 +120,9 @@ class HeadList(list):
     pre_elu = None
 
 
-def _pack_score_operands(layers, x, att, H, Hp, f_in, f_out):
+def _pack_score_operands(layers, x, x_all, att, H, Hp, f_in, f_out):
     """Dense, differentiable (torch ops -> MFMA GEMMs) preparation of the per-node score operands.
+    x: the rows this process owns; x_all: every node a column index can name (== x unsharded).
 
     att 1 (layers.py:349-353):  e = [h_r || h_c] . a,  h = x W   ==  s1[r] + s2[c]
                                 with s1 = x (W a[:F]),  s2 = x (W a[F:])           -> [N,Hp] each
@@ -131,18 +132,15 @@ def _pack_score_operands(layers, x, att, H, Hp, f_in, f_out):
     Returns (rowop, colop, a_vec, F_out_padded).
     """
     if att == 1:
-        cols1 = [l.W @ l.a[:f_out, 0] for l in layers]
-        cols2 = [l.W @ l.a[f_out:, 0] for l in layers]
         zero = [x.new_zeros(f_in)] * (Hp - H)
-        wc = torch.stack(cols1 + zero + cols2 + zero, dim=1)            # [F_in, 2*Hp]
-        s = x @ wc
-        return s[:, :Hp], s[:, Hp:], None, f_out
+        w1 = torch.stack([l.W @ l.a[:f_out, 0] for l in layers] + zero, dim=1)     # [F_in, Hp]
+        w2 = torch.stack([l.W @ l.a[f_out:, 0] for l in layers] + zero, dim=1)
+        return x @ w1, x_all @ w2, None, f_out
     if att == 2:
         f_in_p = (f_in + 3) // 4 * 4
         ms = [F.pad(l.W @ l.W.t(), (0, f_in_p - f_in)) for l in layers]
         ms += [x.new_zeros(f_in, f_in_p)] * (Hp - H)
-        p = x @ torch.cat(ms, dim=1)                                    # [N, Hp*F_in_p]
-        return p, None, None, f_out
+        return x @ torch.cat(ms, dim=1), None, None, f_out                         # [N, Hp*F_in_p]
     g4 = (64 // Hp) * 4
     qn = _pow2ceil((f_out + g4 - 1) // g4)
     if qn > 8:
@@ -151,10 +149,8 @@ def _pack_score_operands(layers, x, att, H, Hp, f_in, f_out):
     fp = qn * g4
     tops = [F.pad(l.W[:f_in], (0, fp - f_out)) for l in layers] + [x.new_zeros(f_in, fp)] * (Hp - H)
     bots = [F.pad(l.W[f_in:], (0, fp - f_out)) for l in layers] + [x.new_zeros(f_in, fp)] * (Hp - H)
-    pq = x @ torch.cat(tops + bots, dim=1)                              # [N, 2*Hp*fp]
-    hf = Hp * fp
     a_vec = torch.cat([F.pad(l.a[:, 0], (0, fp - f_out)) for l in layers] + [x.new_zeros(fp)] * (Hp - H))
-    return pq[:, :hf], pq[:, hf:], a_vec.contiguous(), fp
+    return x @ torch.cat(tops, dim=1), x_all @ torch.cat(bots, dim=1), a_vec.contiguous(), fp
 
 
 def disga_heads(layers, x, adj, aux_indices=None, head_ranges=None):
@@ -186,9 +182,10 @@ def disga_heads(layers, x, adj, aux_indices=None, head_ranges=None):
     f_in_p = (f_in + 3) // 4 * 4
     if f_in_p > 512 or Hp * ((f_in_p + 255) // 256) > 16:
         raise NotImplementedError(f"kernel envelope: F_in={f_in} with {Hp} heads does not fit the register tile")
-    xg = x if (f_in_p == f_in and x.is_contiguous()) else F.pad(x, (0, f_in_p - f_in)).contiguous()
+    x_all = parallel.all_gather_rows(x, graph)       # sharded: one exchange per layer
+    xg = x_all if (f_in_p == f_in and x_all.is_contiguous()) else F.pad(x_all, (0, f_in_p - f_in)).contiguous()
 
-    rowop, colop, a_vec, f_out_p = _pack_score_operands(layers, x, att, H, Hp, f_in, f_out)
+    rowop, colop, a_vec, f_out_p = _pack_score_operands(layers, x, x_all, att, H, Hp, f_in, f_out)
     cfg = (graph, att, Hp, f_in_p, f_out_p, gnn == "SAGE")
     z, edge_e, _den = ops.EdgePass.apply(xg, rowop, colop, a_vec, cfg)
 

@@ -14,6 +14,37 @@ from .graph import CSRGraph
 CHUNK = {1: 256, 2: 256, 3: 128}
 
 
+# bench.py sets PROFILE to a list: every launch is then bracketed by HIP events recorded on the
+# launch stream and logged as (kernel, algorithmic_bytes, start_event, end_event).
+PROFILE = None
+
+
+def _launch(name, label, nbytes, *args):
+    if PROFILE is None:
+        _lib.call(name, *args)
+        return
+    s = torch.cuda.Event(enable_timing=True)
+    e = torch.cuda.Event(enable_timing=True)
+    s.record()
+    _lib.call(name, *args)
+    e.record()
+    PROFILE.append((label, nbytes, s, e))
+
+
+def edge_algorithmic_bytes(att, n, e, H, F_in, F_out):
+    """SURVEY 8(d) B_layer: col index + neighbour row + column-side score operand + edge_e store per
+    edge; layer input read once + per-head output written once per node; rowptr.  (att 2 gathers no
+    column-side operand in this dataflow: S = 0.)"""
+    s = {1: H, 2: 0, 3: H * F_out}[att]
+    return e * (4 + 4 * F_in + 4 * s + 4 * H) + n * (4 * F_in + 4 * H * F_out) + 4 * (n + 1)
+
+
+def aux_algorithmic_bytes(att, n, m, nheads, F_in, F_out):
+    """SURVEY 8(d) B_aux: index pair + column-side operand per pair; row-side operand once per node."""
+    s = {1: nheads, 2: F_in, 3: nheads * F_out}[att]
+    return m * (8 + 4 * s) + n * 4 * s
+
+
 def _ptr(t):
     return 0 if t is None else t.data_ptr()
 
@@ -55,7 +86,8 @@ def edge_forward(graph: CSRGraph, att, H, F_in, F_out, x, rowop, colop, a, sage_
         part_z = torch.empty((wi.n_slots, H, F_in), dtype=torch.float32, device=dev)
         part_den = torch.empty((wi.n_slots, H), dtype=torch.float32, device=dev)
     st = _stream()
-    _lib.call("disgat_edge_fwd", att, _ptr(wi.items), wi.n_items, _ptr(graph.col), e, n, H, F_in, F_out,
+    _launch("disgat_edge_fwd", f"edge_fwd_att{att}", edge_algorithmic_bytes(att, n, e, H, F_in, F_out),
+            att, _ptr(wi.items), wi.n_items, _ptr(graph.col), e, n, H, F_in, F_out,
               _ptr(x), x.stride(0), _ptr(rowop), rowop.stride(0), _ptr(colop), 0 if colop is None else colop.stride(0),
               _ptr(a), _ptr(z), _ptr(edge_e), _ptr(den), _ptr(part_z), _ptr(part_den), int(bool(sage_div)), st)
     if wi.n_split:
@@ -73,7 +105,8 @@ def aux_forward(att, H, F_in, F_out, pairs, n, x, rowop, colop, a, h_lo=0, h_hi=
     pairs = pairs.contiguous()
     m = int(pairs.shape[1])
     out = torch.empty((H, m), dtype=torch.float32, device=pairs.device)
-    _lib.call("disgat_aux_score", att, pairs[0].data_ptr(), pairs[1].data_ptr(), m, n, H, F_in, F_out, h_lo, h_hi,
+    _launch("disgat_aux_score", f"aux_score_att{att}", aux_algorithmic_bytes(att, n, m, h_hi - h_lo, F_in, F_out),
+            att, pairs[0].data_ptr(), pairs[1].data_ptr(), m, n, H, F_in, F_out, h_lo, h_hi,
               _ptr(x), 0 if x is None else x.stride(0), _ptr(rowop), rowop.stride(0),
               _ptr(colop), 0 if colop is None else colop.stride(0), _ptr(a), _ptr(out), _stream())
     return out

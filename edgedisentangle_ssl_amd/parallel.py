@@ -1,0 +1,105 @@
+"""Row-range sharding of the DISGAT path across the GPUs of one MI355X node.
+
+One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI on ROCm, "gloo" in the
+CPU tests).  Softmax and aggregation are row-local, so rank g owns a contiguous range of CSR rows
+(balanced by nnz, not by row count: power-law skew) and needs, per layer, only the COLUMN-side
+operands of the neighbours its rows reference.  For the random-column graphs of BASELINE.json the
+halo is ~all of N, so the exchange is one all-gather of the layer input x per layer
+(N*F_in*4 bytes in total, 1/G of it sent by each rank - not an all-reduce of zero-padded buffers,
+which would move G x more); the column-side score operand (att 3: Q = x W_bot, H*F_out wide) is
+then recomputed locally from the gathered x instead of being exchanged (8x fewer bytes on the
+per-link-bound xGMI mesh; the redundant GEMM is cheaper than 7 links x ~50 GB/s).  Loss terms
+reduce with one all-reduce of three doubles.
+"""
+import torch
+import torch.distributed as dist
+
+from .graph import CSRGraph
+
+
+def balanced_row_ranges(rowptr, world):
+    """Row boundaries [world+1] such that every range holds ~nnz/world entries."""
+    rp = rowptr.to(torch.int64)
+    n = rp.numel() - 1
+    nnz = int(rp[-1])
+    targets = torch.arange(1, world, device=rp.device, dtype=torch.int64) * nnz // world
+    cuts = torch.searchsorted(rp, targets, right=False).clamp_(0, n)
+    b = torch.cat([torch.zeros(1, dtype=torch.int64, device=rp.device), cuts,
+                   torch.full((1,), n, dtype=torch.int64, device=rp.device)])
+    return torch.cummax(b, 0).values
+
+
+class DistGraph(CSRGraph):
+    """CSR of the rows this rank owns: LOCAL row ids, GLOBAL column ids."""
+
+    def __init__(self, n_local, rowptr, col, row, n_global, row_start, counts, group=None):
+        super().__init__(n_local, rowptr, col, row)
+        self.n_global = int(n_global)
+        self.row_start = int(row_start)
+        self.counts = [int(c) for c in counts]          # rows owned by every rank
+        self.group = group
+        self.world = len(self.counts)
+
+    @staticmethod
+    def from_local_edges(local_rows, global_cols, n_local, n_global, row_start, counts, group=None):
+        flat = torch.unique(local_rows.to(torch.int64) * n_global + global_cols.to(torch.int64))
+        row = torch.div(flat, n_global, rounding_mode="floor")
+        col = (flat - row * n_global).to(torch.int32)
+        rp = torch.zeros(n_local + 1, dtype=torch.int64, device=flat.device)
+        rp[1:] = torch.cumsum(torch.bincount(row, minlength=n_local), 0)
+        return DistGraph(n_local, rp.to(torch.int32).contiguous(), col.contiguous(), row.contiguous(), n_global,
+                         row_start, counts, group)
+
+    @staticmethod
+    def shard(graph, rank, world, group=None):
+        """Cut a replicated global CSRGraph into this rank's row range (tests / small graphs)."""
+        b = balanced_row_ranges(graph.rowptr, world)
+        lo, hi = int(b[rank]), int(b[rank + 1])
+        rp = graph.rowptr.to(torch.int64)
+        e0, e1 = int(rp[lo]), int(rp[hi])
+        counts = (b[1:] - b[:-1]).tolist()
+        return DistGraph(hi - lo, (rp[lo:hi + 1] - e0).to(torch.int32).contiguous(), graph.col[e0:e1].contiguous(),
+                         (graph.row[e0:e1] - lo).contiguous(), graph.n, lo, counts, group)
+
+    def transpose(self):
+        raise NotImplementedError("backward over a sharded graph is not built yet (SURVEY 8f-1)")
+
+
+class _AllGatherRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, counts, group):
+        ctx.counts, ctx.group = counts, group
+        world = len(counts)
+        rank = dist.get_rank(group)
+        if len(set(counts)) == 1:
+            out = x.new_empty((counts[0] * world,) + tuple(x.shape[1:]))
+            dist.all_gather_into_tensor(out, x.contiguous(), group=group)
+            return out
+        mx = max(counts)
+        pad = x.new_zeros((mx,) + tuple(x.shape[1:]))
+        pad[: counts[rank]] = x
+        bufs = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(bufs, pad, group=group)
+        return torch.cat([b[:c] for b, c in zip(bufs, counts)], 0)
+
+    @staticmethod
+    def backward(ctx, g):
+        counts, group = ctx.counts, ctx.group
+        rank = dist.get_rank(group)
+        g = g.contiguous()
+        dist.all_reduce(g, group=group)
+        lo = sum(counts[:rank])
+        return g[lo: lo + counts[rank]], None, None
+
+
+def all_gather_rows(x_local, graph):
+    """[n_local,F] on every rank -> [n_global,F] (rank order = row order).  Identity when unsharded."""
+    if not isinstance(graph, DistGraph) or graph.world == 1:
+        return x_local
+    return _AllGatherRows.apply(x_local, graph.counts, graph.group)
+
+
+def all_reduce_sum(t, graph):
+    if isinstance(graph, DistGraph) and graph.world > 1:
+        dist.all_reduce(t, group=graph.group)
+    return t

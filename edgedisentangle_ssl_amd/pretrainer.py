@@ -1,0 +1,224 @@
+"""SupEdge / DisEdge / DifHead self-supervised trainers on the DISGAT path.
+
+Mirrors of /root/reference/pretrainer.py:658-776 (SupEdgeTrainer), :372-654
+(GeneratedEdgeTrainer) and :780-857 (DifHeadTrainer) plus the Trainer base of
+trainer.py:35-80: same class names, constructor signature (args, model, weight), attributes
+(fuse1/fuse2, models, models_opt), log keys and loss arithmetic.  Differences, all on the input
+side of the hot path:
+  * the reference samples training pairs through dense N x N masks (pretrainer.py:683-707,
+    524-576); here the same distribution (Bernoulli(3*rho) over all entries united with a third
+    of the positives, row-major order) is drawn in O(E) on the device (sampling.py);
+  * `loss(...)` exposes the forward + loss part of train_step on pre-sampled pairs (what bench.py
+    times); train_step = sample + loss + backward + optimiser steps as in the reference.
+"""
+import torch
+import torch.nn.functional as F
+import torch.optim as optim
+
+from . import ops, parallel, sampling
+from .graph import graph_of
+from .layers import FuseLayer
+from .models import MLP
+from .utils import adj_mse_loss
+
+
+def pair_mse_loss(aux, h_lo, h_hi, labels, graph=None):
+    """pred = sigmoid(sum_{h in [lo,hi)} aux_h); utils.adj_mse_loss(pred, labels) on 1-D input
+    (pretrainer.py:734-739, 619-627).  aux: list of H [M,1] tensors (entries outside the range may
+    be None).  Without autograd the reduction runs in the HIP pair-loss kernel; on a sharded graph
+    the three partial sums and the pair count are all-reduced (the loss is global)."""
+    heads = [aux[h] for h in range(h_lo, h_hi)]
+    base = heads[0]._base
+    sharded = isinstance(graph, parallel.DistGraph) and graph.world > 1
+    fused = (base is not None and base.dim() == 2 and base.is_contiguous() and base.shape[1] == labels.shape[0]
+             and heads[0].data_ptr() == base[h_lo].data_ptr())
+    if fused and not (torch.is_grad_enabled() and any(h.requires_grad for h in heads)):
+        acc = ops.pair_loss_sums(base, h_lo, h_hi, labels)
+        acc = torch.cat([acc, torch.tensor([float(labels.shape[0])], dtype=torch.float64, device=acc.device)])
+        parallel.all_reduce_sum(acc, graph)
+        m = acc[3]
+        neg_w = acc[2] / (m * m - acc[2])
+        return ((acc[0] + neg_w * acc[1]) / m).to(torch.float32)
+    if sharded:
+        raise NotImplementedError("differentiable pair loss over a sharded graph is not built yet")
+    pred = torch.sigmoid(torch.sum(torch.stack(heads), dim=0))
+    return adj_mse_loss(pred.squeeze(-1), labels)
+
+
+class Trainer(object):
+    """trainer.py:35-60: owns one fuser pair per trainer and one Adam per sub-module."""
+
+    def __init__(self, args, model, weight):
+        self.args = args
+        self.loss_weight = weight
+        self.models = [model]
+        res = (args.size, args.nhid) if args.residue else (0, 0)
+        self.fuse1 = FuseLayer(args, args.nhead, nfeat=args.nhid, residue=res[0])
+        self.fuse2 = FuseLayer(args, args.nhead, nfeat=args.nhid, residue=res[1])
+        dev = next(model.parameters()).device
+        self.fuse1.to(dev)
+        self.fuse2.to(dev)
+        self.models += [self.fuse1, self.fuse2]
+        self.models_opt = [optim.Adam(m.parameters(), lr=args.lr, weight_decay=args.weight_decay) for m in self.models]
+
+    def _begin_step(self):
+        for i, model in enumerate(self.models):
+            model.train()
+            self.models_opt[i].zero_grad()
+
+    def _finish_step(self, loss):
+        (loss * self.loss_weight).backward()
+        if self.loss_weight != 0:
+            for opt in self.models_opt:
+                opt.step()
+
+    def _layer_on(self, i):
+        return self.constrain_layer == 0 or self.constrain_layer == i       # pretrainer.py:597, 728
+
+
+class SupEdgeTrainer(Trainer):
+    """Edge-recovery supervision on the sum of all heads (pretrainer.py:658-776)."""
+
+    def __init__(self, args, model, weight):
+        super().__init__(args, model, weight)
+        assert args.model == "DISGAT", "supervision on edges can only be conducted on DISGAT model"
+        self.sparse = args.sparse
+        self.constrain_layer = args.constrain_layer
+
+    def get_label_all(self, feature, adj):
+        """The reference returns a dense 0/1 N x N tensor (pretrainer.py:667-680); the positive set
+        is kept as the CSR graph instead."""
+        return graph_of(adj)
+
+    def sample_train(self, gt):
+        g = graph_of(gt)
+        idx, lab = sampling.sample_pairs(g.n, sampling.flat_edges(g))
+        return lab, [idx]
+
+    def inference(self, data, sparse_edge_index=None):
+        feature, adj = data
+        return self.models[0].predict_adjs_sparse(feature, adj, [self.fuse1, self.fuse2],
+                                                  auxiliary_edges=sparse_edge_index)
+
+    def loss(self, data, labels, indices):
+        pred_adjs = self.inference(data, indices)
+        loss = None
+        nh = self.args.nhead
+        for i, pred_adj in enumerate(pred_adjs):
+            if self._layer_on(i):
+                term = pair_mse_loss([head[0] for head in pred_adj], 0, nh, labels, graph_of(data[1]))
+                loss = term if loss is None else loss + term
+        return loss
+
+    def train_step(self, data, gt_adj=None):
+        self._begin_step()
+        labels, indices = self.sample_train(gt_adj if gt_adj is not None else data[1])
+        loss = self.loss(data, labels, indices)
+        self._finish_step(loss)
+        return {"loss_heads_sup": loss.item()}
+
+
+class GeneratedEdgeTrainer(Trainer):
+    """Homo / hetero edge disentanglement: first H/2 heads vs same-label edges, last H/2 heads vs
+    different-label edges (pretrainer.py:372-654)."""
+
+    def __init__(self, args, model, weight):
+        super().__init__(args, model, weight)
+        self.dis_type = args.dis_type
+        self.constrain_layer = args.constrain_layer
+        self.sparse = args.sparse
+        self.dis_adjs = []
+        self.labels = None
+
+    def get_label_all(self, feature, adj, labels, load=True):
+        """Flat positive sets of the two edge groups (pretrainer.py:448-456) - O(E), nothing cached
+        on disk (the reference pickles a dense 2 x N x N tensor)."""
+        assert self.dis_type == 1, "currently only use homo&hetero edge disentanglement"
+        g = graph_of(adj)
+        self.labels = labels
+        same = labels[g.row] == labels[g.col.long()]
+        flat = sampling.flat_edges(g)
+        self.n = g.n
+        self.dis_adjs = [flat[same], flat[~same]]
+        return self.dis_adjs
+
+    def sample_train(self):
+        labs, idxs = [], []
+        for pos in self.dis_adjs:
+            idx, lab = sampling.sample_pairs(self.n, pos)
+            labs.append(lab)
+            idxs.append(idx)
+        return labs, idxs
+
+    def inference(self, data, sparse_edge_index=None, head_ranges=None):
+        feature, adj = data
+        return self.models[0].predict_adjs_sparse(feature, adj, [self.fuse1, self.fuse2],
+                                                  auxiliary_edges=sparse_edge_index, head_ranges=head_ranges)
+
+    def loss(self, data, adj_labels, adj_masks):
+        nh = self.args.nhead
+        half = int(nh / 2)
+        # only the supervised half of the heads is scored on each list (the reference scores all)
+        pred_adjs = self.inference(data, adj_masks, head_ranges=[(0, half), (half, nh)])
+        loss = None
+        for i, pred_adj in enumerate(pred_adjs):
+            if self._layer_on(i):
+                g = graph_of(data[1])
+                term = (pair_mse_loss([head[0] for head in pred_adj], 0, half, adj_labels[0], g)
+                        + pair_mse_loss([head[1] for head in pred_adj], half, nh, adj_labels[1], g))
+                loss = term if loss is None else loss + term
+        return loss
+
+    def train_step(self, data, pre_adjs=None):
+        assert self.dis_type == 1, "currently only use homo&hetero edge disentanglement"
+        self._begin_step()
+        adj_labels, adj_masks = self.sample_train()
+        loss = self.loss(data, adj_labels, adj_masks)
+        self._finish_step(loss)
+        return {"loss_head_disen": loss.item()}
+
+
+class DifHeadTrainer(Trainer):
+    """Head-diversity: an MLP must recognise which head produced cat(layer_input, head_output)
+    (pretrainer.py:780-857)."""
+
+    def __init__(self, args, model, weight):
+        super().__init__(args, model, weight)
+        assert args.model == "DISGAT", "divergence on heads is only supported for DISGAT"
+        dev = next(model.parameters()).device
+        self.classifier1 = MLP(in_feat=args.nhid + args.size, hidden_size=args.nhid, out_size=args.nhead,
+                               layers=args.cls_layer).to(dev)
+        self.classifier2 = MLP(in_feat=args.nhid * 2, hidden_size=args.nhid, out_size=args.nhead,
+                               layers=args.cls_layer).to(dev)
+        for c in (self.classifier1, self.classifier2):
+            self.models.append(c)
+            self.models_opt.append(optim.Adam(c.parameters(), lr=args.lr, weight_decay=args.weight_decay))
+        self.nhead = args.nhead
+
+    def get_label_all(self, feature, adj):
+        return None
+
+    def inference(self, data):
+        feature, adj = data
+        return self.models[0].get_edge_em(feature, adj, [self.fuse1, self.fuse2])
+
+    def loss(self, data):
+        edge_embeds = self.inference(data)
+        loss = None
+        for layer, edge_embed in enumerate(edge_embeds):
+            classifier = self.classifier1 if layer == 0 else self.classifier2
+            for i, edge in enumerate(edge_embed):
+                pred_label = classifier(edge, cls=True)
+                g = graph_of(data[1])
+                if isinstance(g, parallel.DistGraph) and g.world > 1:   # global mean over all ranks' nodes
+                    term = -parallel.all_reduce_sum(pred_label[:, i].sum(), g) / g.n_global
+                else:
+                    term = -pred_label[:, i].mean()             # NLLLoss against the constant label i
+                loss = term if loss is None else loss + term
+        return loss
+
+    def train_step(self, data, pre_dif=None):
+        self._begin_step()
+        loss = self.loss(data)
+        self._finish_step(loss)
+        return {"loss_head_diversity": loss.item()}
