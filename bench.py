@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--att", type=int, default=3)
     ap.add_argument("--gnn_type", default="AT")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-nodes", type=int, default=8192)
+    ap.add_argument("--cpu-nodes", type=int, default=2048)
     ap.add_argument("--fwd-only", action="store_true", help="time one get_em (T_fwd) instead of T_iter")
     return ap.parse_args()
 
@@ -157,9 +157,11 @@ def cpu_baseline(o):
             l3 = orc.dif_head_loss(r["edge_em"], c1, c2)
         return float(l1 + l2 + l3)
 
+    print(f"[bench] cpu_baseline: oracle on N={n} nnz={graph.nnz}, {torch.get_num_threads()} threads ...", file=sys.stderr, flush=True)
     t0 = time.time()
     step()
     t1 = time.time() - t0
+    print(f"[bench] cpu_baseline warm-up step {t1:.1f}s", file=sys.stderr, flush=True)
     reps = 1 if t1 > 12 else 2
     t0 = time.time()
     for _ in range(reps):
