@@ -1,0 +1,125 @@
+"""CPU-only checks of the host logic and of the C-ABI library (load + exported symbols; no
+compute calls without a GPU)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import inputs_common as ic
+
+
+def test_library_builds_loads_and_exports_header_symbols():
+    from edgedisentangle_ssl_amd import _lib
+    path = _lib.build()
+    lib = ctypes.CDLL(path)
+    hdr = open(os.path.join(os.path.dirname(__file__), "..", "include", "disgat_hip.h")).read()
+    declared = sorted(set(re.findall(r"^\s*(?:int|const char\*)\s+(disgat_\w+)\s*\(", hdr, flags=re.M)))
+    assert declared, "no declarations parsed from the header"
+    for sym in declared:
+        assert hasattr(lib, sym), f"{sym} declared in include/disgat_hip.h but not exported"
+    assert declared == _lib.exported_symbols(), (declared, _lib.exported_symbols())
+    lib.disgat_abi_version.restype = ctypes.c_int
+    assert lib.disgat_abi_version() >= 1
+
+
+def test_csr_and_work_items_cover_every_edge_once():
+    from edgedisentangle_ssl_amd.graph import CSRGraph
+    idx, vals, n = ic.tiny_graph()
+    g = CSRGraph.from_index(idx, n)
+    ci = ic.coalesced_index_set(idx, n)
+    assert torch.equal(g.indices(), ci)                      # CSR order == coalesce() order
+    assert int(g.rowptr[-1]) == g.nnz == ci.shape[1]
+    for chunk in (4, 8, 64, 1024):
+        wi = g.work_items(chunk)
+        it = wi.items.long()
+        assert it.shape == (wi.n_items, 4)
+        lens = it[:, 2] - it[:, 1]
+        assert int(lens.max()) <= chunk and int(lens.sum()) == g.nnz
+        assert torch.all(lens[:-1] >= lens[1:])              # descending length
+        cover = torch.zeros(g.nnz, dtype=torch.int64)
+        for r, b, e, s in it.tolist():
+            cover[b:e] += 1
+            assert int(g.rowptr[r]) <= b <= e <= int(g.rowptr[r + 1])
+        assert torch.all(cover == 1)
+        rows_seen = torch.bincount(it[:, 0], minlength=n)
+        assert torch.all(rows_seen >= 1)                     # empty rows keep one (empty) item
+        split = it[it[:, 3] >= 0]
+        assert sorted(split[:, 3].tolist()) == list(range(wi.n_slots))
+        sp = wi.split_ptr.long()
+        for k, r in enumerate(wi.split_rows.tolist()):
+            slots = sorted(split[split[:, 0] == r][:, 3].tolist())
+            assert slots == list(range(int(sp[k]), int(sp[k + 1])))
+
+
+def test_transpose_structure():
+    from edgedisentangle_ssl_amd.graph import CSRGraph
+    idx, vals, n = ic.tiny_graph()
+    g = CSRGraph.from_index(idx, n)
+    t = g.transpose()
+    # entry j of the transpose: column c (CSC order), source row t.col[j], forward edge id t.eid[j]
+    eid = t.eid.long()
+    assert torch.equal(g.col.long()[eid], t.row)
+    assert torch.equal(g.row[eid], t.col.long())
+    assert sorted(eid.tolist()) == list(range(g.nnz))
+
+
+def test_sampler_matches_reference_structure(golden_dir):
+    from edgedisentangle_ssl_amd import sampling
+    from edgedisentangle_ssl_amd.graph import CSRGraph
+    idx, vals, n = ic.tiny_graph()
+    g = CSRGraph.from_index(idx, n)
+    pos = sampling.flat_edges(g)
+    gen = torch.Generator().manual_seed(3)
+    pidx, lab = sampling.sample_pairs(n, pos, gen)
+    flat = pidx[0] * n + pidx[1]
+    assert torch.all(flat[1:] > flat[:-1])                   # row-major, unique (mask.nonzero() order)
+    assert torch.equal(lab, torch.isin(flat, pos).float())
+    assert int(lab.sum()) >= g.nnz // 3
+    ref = np.load(os.path.join(golden_dir, "tiny_ref_sampler.npz"))
+    assert 0.5 < pidx.shape[1] / ref["sup_idx"].shape[1] < 2.0
+
+
+def test_adj_mse_loss_quirk(golden_dir):
+    from edgedisentangle_ssl_amd.utils import adj_mse_loss
+    g = np.load(os.path.join(golden_dir, "prims.npz"))
+    rec, tgt = torch.from_numpy(g["mse_rec"]), torch.from_numpy(g["mse_tgt"])
+    assert abs(float(adj_mse_loss(rec, tgt)) - float(g["mse_1d"])) < 1e-7
+    assert abs(float(adj_mse_loss(rec[:400].reshape(20, 20), tgt[:400].reshape(20, 20))) - float(g["mse_2d"])) < 1e-7
+
+
+def test_parser_surface():
+    from edgedisentangle_ssl_amd.utils import get_parser
+    a = get_parser().parse_args("--model=DISGAT --gnn_type SAGE --att 3 --nhead 8 --sparse --pretrain SupEdge DisEdge "
+                                "DifHead --pre_weight 100 1 0 --pre_edge 1 1 1 --downstream CLS --down_weight 1.0 "
+                                "--finetune --constrain_layer 0 --steps 5 --dataset cora_full".split())
+    assert a.model == "DISGAT" and a.gnn_type == "SAGE" and a.att == 3 and a.nhead == 8 and a.sparse
+    assert a.pretrain == ["SupEdge", "DisEdge", "DifHead"] and a.pre_weight == [100.0, 1.0, 0.0]
+    d = get_parser().parse_args([])
+    assert (d.att, d.nhead, d.nhid, d.dropout, d.gnn_type, d.seed, d.lr) == (2, 4, 64, 0.1, "AT", 4, 0.01)
+
+
+def test_state_dict_keys_match_reference_layout():
+    from types import SimpleNamespace
+    from edgedisentangle_ssl_amd import DISGAT
+    from test_oracle_golden import shapes_disgat
+    for gnn in ("AT", "SAGE", "GCN"):
+        for att in (1, 2, 3):
+            a = SimpleNamespace(gnn_type=gnn, att=att, residue=False, residue_type=0, fuse_no_relu=False)
+            m = DISGAT(a, nfeat=12, nhid=8, nclass=8, nheads=3, dropout=0.0)
+            got = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+            assert got == shapes_disgat(gnn, att, 12, 8, 3)
+
+
+def test_cpu_tensors_are_refused():
+    from types import SimpleNamespace
+    import edgedisentangle_ssl_amd as pkg
+    a = SimpleNamespace(gnn_type="AT", att=3, residue=False, residue_type=0, fuse_no_relu=False)
+    enc = pkg.DISGAT(a, nfeat=16, nhid=16, nclass=16, nheads=4, dropout=0.0)
+    idx, vals, n = ic.tiny_graph()
+    adj = torch.sparse_coo_tensor(idx, vals, (n, n))
+    fus = [pkg.FuseLayer(a, 4, nfeat=16), pkg.FuseLayer(a, 4, nfeat=16)]
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        enc.get_em(ic.features(21, n, 16), adj, fus)
