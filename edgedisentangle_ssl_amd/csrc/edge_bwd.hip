@@ -1,0 +1,472 @@
+// Backward of the fused DISGAT edge pass and of the aux-pair scorer for gfx950.
+//
+// The reference gets these gradients from ATen autograd through index / cat / mm /
+// scatter_add_ (loss.backward() at pretrainer.py:752, 631, 836; trainer.py:200).  Here they are
+// gather-only segment passes over work items (no float atomics except for the few split hub
+// segments), reusing the forward's lane maps:
+//
+//  bwd_alpha_kernel     per CSR row r, head h, with s = sigmoid(e), w = exp(s), alpha = w/den:
+//                         galpha_k = sc * <gZ[r,h,:], x[col_k,:]>          (Z = sc * sum_k alpha_k x[col_k])
+//                         t        = sum_k alpha_k galpha_k = <gZ[r,h,:], Z[r,h,:]>   (no second sweep)
+//                         ge_k     = ge_in_k + alpha_k (galpha_k - t) * s_k (1 - s_k)
+//                       writes ge[H][E] and beta[H][E] = alpha*sc (coefficients of the transposed pass).
+//  seg_grad_att3_kernel e = sum_f a_f lrelu(P[key] + Q[other]):  gkey[key] = sum_m g_m a lrelu'(z_m),
+//                       ga += sum_m g_m lrelu(z_m).  Symmetric in P and Q, so the same kernel gives gP
+//                       (segments = CSR rows / row-sorted aux pairs) and gQ (segments = CSC columns /
+//                       column-sorted aux pairs, g read through a permutation).
+//  seg_grad_hx_row      gkey[key,h,:] = sum_m coef[h,m] X[other_m,:]        (att 2: gP)
+//  seg_grad_hx_col      gkey[key,:] (+)= sum_m sum_h coef[h,m] Mx[other_m,h,:]   (gx from beta*gZ; att 2: ge*P)
+//
+// Segments longer than the chunk are split over several work items (slot >= 0); those add into
+// rows the host has zeroed, everything else is a plain store by the single owner of the row.
+#include "disgat_common.h"
+
+namespace disgat {
+
+__device__ __forceinline__ void out4(float* p, f32x4 v, bool atomic, bool accumulate) {
+  if (atomic) {
+    atomicAdd(p + 0, v.x);
+    atomicAdd(p + 1, v.y);
+    atomicAdd(p + 2, v.z);
+    atomicAdd(p + 3, v.w);
+  } else if (accumulate) {
+    st4(p, ld4(p) + v);
+  } else {
+    st4(p, v);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+struct BwdAlphaArgs {
+  const int4* items;
+  int n_items;
+  const int32_t* col;
+  int64_t E;
+  int F_in;
+  const float* x;
+  int ldx;
+  const float* gZ;      // [N][H][F_in]
+  const float* Z;       // [N][H][F_in]
+  const float* edge_e;  // [H][E]
+  const float* den;     // [N][H]
+  const float* ge_in;   // [H][E] or null
+  float* ge_out;        // [H][E]
+  float* beta;          // [H][E]
+  int sage_div;
+};
+
+template <int HL, int XN>
+__global__ __launch_bounds__(DISGAT_BLOCK, 2) void bwd_alpha_kernel(const BwdAlphaArgs A) {
+  constexpr int H = 1 << HL;
+  const int lane = threadIdx.x & 63;
+  const int item = blockIdx.x * DISGAT_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+  if (item >= A.n_items) return;
+  const int4 it = A.items[item];
+  const int row = rfl(it.x), kb = rfl(it.y), ke = rfl(it.z);
+  if (kb >= ke) return;
+  const int myh = lane & (H - 1);
+  const int xoff = lane * 4;
+
+  f32x4 gz[H * XN];
+  float tsel = 0.f;
+  {
+    const float* gp = A.gZ + (size_t)row * (H * A.F_in);
+    const float* zp = A.Z + (size_t)row * (H * A.F_in);
+#pragma unroll
+    for (int hh = 0; hh < H; ++hh) {
+      float acc = 0.f;
+#pragma unroll
+      for (int i = 0; i < XN; ++i) {
+        const int o = i * 256 + xoff;
+        const bool ok = o < A.F_in;
+        gz[hh * XN + i] = ok ? ld4(gp + hh * A.F_in + o) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 zz = ok ? ld4(zp + hh * A.F_in + o) : f32x4{0.f, 0.f, 0.f, 0.f};
+        acc = dot4(gz[hh * XN + i], zz, acc);
+      }
+      acc = group_sum<6>(acc);
+      tsel = (myh == hh) ? acc : tsel;
+    }
+  }
+  const float den = A.den[(size_t)row * H + myh];
+  const float inv = (den > 0.f) ? 1.0f / den : 0.f;
+  const float scs = A.sage_div ? 1.0f / (den * inv + 1.0f) : 1.0f;
+
+  f32x4 xA[XN], xB[XN];
+  auto load_x = [&](f32x4(&xv)[XN], int c) {
+    const float* xp = A.x + (size_t)c * A.ldx + xoff;
+#pragma unroll
+    for (int i = 0; i < XN; ++i) xv[i] = (i * 256 + xoff < A.F_in) ? ld4(xp + i * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  auto compute = [&](const f32x4(&xv)[XN], int64_t k) {
+    float gal = 0.f;
+#pragma unroll
+    for (int hh = 0; hh < H; ++hh) {
+      float acc = 0.f;
+#pragma unroll
+      for (int i = 0; i < XN; ++i) acc = dot4(gz[hh * XN + i], xv[i], acc);
+      acc = group_sum<6>(acc);
+      gal = (myh == hh) ? acc : gal;
+    }
+    if (lane < H) {
+      const int64_t o = (int64_t)myh * A.E + k;
+      const float e = A.edge_e[o];
+      const float s = sigmoidf_(e);
+      const float alpha = expf(s) * inv;
+      const float gs = alpha * (scs * gal - tsel);
+      float g = gs * s * (1.0f - s);
+      if (A.ge_in != nullptr) g += A.ge_in[o];
+      A.ge_out[o] = g;
+      A.beta[o] = alpha * scs;
+    }
+  };
+  for (int kbase = kb; kbase < ke; kbase += 64) {
+    const int cnt = min(64, ke - kbase);
+    const int cv = (lane < cnt) ? A.col[kbase + lane] : 0;
+    load_x(xA, __builtin_amdgcn_readlane(cv, 0));
+    int i = 0;
+    for (; i + 1 < cnt; i += 2) {
+      load_x(xB, __builtin_amdgcn_readlane(cv, i + 1));
+      compute(xA, (int64_t)kbase + i);
+      if (i + 2 < cnt) load_x(xA, __builtin_amdgcn_readlane(cv, i + 2));
+      compute(xB, (int64_t)kbase + i + 1);
+    }
+    if (i < cnt) compute(xA, (int64_t)kbase + i);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+struct SegArgs {
+  const int4* items;     // {key, m_begin, m_end, slot}
+  int n_items;
+  const int32_t* other;  // [M] index of the gathered operand per list position
+  const int32_t* perm;   // [M] or null: position in g/coef of list position m
+  const float* g;        // [H][g_stride]
+  int64_t g_stride;
+  int h_lo, h_hi;
+  int F;                 // hx kernels: floats per (node, head) row (multiple of 4)
+  const float* keyop;
+  int ld_key;
+  const float* otherop;
+  int ld_other;
+  const float* a;
+  float* gkey;
+  int ld_gkey;
+  float* ga_part;        // [n_waves][H*FQ] or null
+  int accumulate;
+};
+
+template <int HL, int QN>
+__global__ __launch_bounds__(DISGAT_BLOCK, 2) void seg_grad_att3_kernel(const SegArgs A) {
+  constexpr int GL = 6 - HL;
+  constexpr int G = 1 << GL;
+  constexpr int FQ = QN * G * 4;
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * DISGAT_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+  const int n_waves = gridDim.x * DISGAT_WAVES_PER_BLOCK;
+  const int myh = lane >> GL;
+  const bool active = (myh >= A.h_lo) && (myh < A.h_hi);
+  const int qoff = myh * FQ + (lane & (G - 1)) * 4;
+
+  f32x4 a_r[QN], ga[QN];
+#pragma unroll
+  for (int j = 0; j < QN; ++j) {
+    a_r[j] = ld4(A.a + qoff + j * G * 4);
+    ga[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  for (int item = wave; item < A.n_items; item += n_waves) {   // persistent: ga stays in registers
+    const int4 it = A.items[item];
+    const int key = rfl(it.x), mb = rfl(it.y), me = rfl(it.z), slot = rfl(it.w);
+    f32x4 p_r[QN], gk[QN], qA[QN], qB[QN];
+    {
+      const float* pp = A.keyop + (size_t)key * A.ld_key + qoff;
+#pragma unroll
+      for (int j = 0; j < QN; ++j) {
+        p_r[j] = active ? ld4(pp + j * G * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        gk[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    auto load_q = [&](f32x4(&q)[QN], int o) {
+      if (active) {
+        const float* qp = A.otherop + (size_t)o * A.ld_other + qoff;
+#pragma unroll
+        for (int j = 0; j < QN; ++j) q[j] = ld4(qp + j * G * 4);
+      }
+    };
+    auto compute = [&](const f32x4(&q)[QN], int gpos) {
+      if (active) {
+        const float gv = A.g[(int64_t)myh * A.g_stride + gpos];
+#pragma unroll
+        for (int j = 0; j < QN; ++j) {
+          const f32x4 z = p_r[j] + q[j];
+          f32x4 l, d;
+          l.x = lrelu001(z.x); l.y = lrelu001(z.y); l.z = lrelu001(z.z); l.w = lrelu001(z.w);
+          d.x = z.x > 0.f ? 1.f : 0.01f; d.y = z.y > 0.f ? 1.f : 0.01f;
+          d.z = z.z > 0.f ? 1.f : 0.01f; d.w = z.w > 0.f ? 1.f : 0.01f;
+          ga[j] += gv * l;
+          gk[j] += (gv * a_r[j]) * d;
+        }
+      }
+    };
+    for (int mbase = mb; mbase < me; mbase += 64) {
+      const int cnt = min(64, me - mbase);
+      const int ov = (lane < cnt) ? A.other[mbase + lane] : 0;
+      const int pv = (lane < cnt) ? (A.perm ? A.perm[mbase + lane] : mbase + lane) : 0;
+      load_q(qA, __builtin_amdgcn_readlane(ov, 0));
+      int i = 0;
+      for (; i + 1 < cnt; i += 2) {
+        load_q(qB, __builtin_amdgcn_readlane(ov, i + 1));
+        compute(qA, __builtin_amdgcn_readlane(pv, i));
+        if (i + 2 < cnt) load_q(qA, __builtin_amdgcn_readlane(ov, i + 2));
+        compute(qB, __builtin_amdgcn_readlane(pv, i + 1));
+      }
+      if (i < cnt) compute(qA, __builtin_amdgcn_readlane(pv, i));
+    }
+    float* op = A.gkey + (size_t)key * A.ld_gkey + qoff;
+#pragma unroll
+    for (int j = 0; j < QN; ++j) out4(op + j * G * 4, gk[j], slot >= 0, A.accumulate != 0);
+  }
+  if (A.ga_part != nullptr) {
+    float* gp = A.ga_part + (size_t)wave * (FQ << HL) + qoff;
+#pragma unroll
+    for (int j = 0; j < QN; ++j) st4(gp + j * G * 4, ga[j]);
+  }
+}
+
+// gkey[key][h][:] = sum_m coef[h][pos(m)] * X[other_m][:]
+template <int HL, int XN>
+__global__ __launch_bounds__(DISGAT_BLOCK, 2) void seg_grad_hx_row_kernel(const SegArgs A) {
+  constexpr int H = 1 << HL;
+  const int lane = threadIdx.x & 63;
+  const int item = blockIdx.x * DISGAT_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+  if (item >= A.n_items) return;
+  const int4 it = A.items[item];
+  const int key = rfl(it.x), mb = rfl(it.y), me = rfl(it.z), slot = rfl(it.w);
+  const int xoff = lane * 4;
+  const int myh = lane & (H - 1);
+  const bool hact = (myh >= A.h_lo) && (myh < A.h_hi);
+  f32x4 acc[H * XN], xA[XN], xB[XN];
+#pragma unroll
+  for (int i = 0; i < H * XN; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto load_x = [&](f32x4(&xv)[XN], int o) {
+    const float* xp = A.otherop + (size_t)o * A.ld_other + xoff;
+#pragma unroll
+    for (int i = 0; i < XN; ++i) xv[i] = (i * 256 + xoff < A.F) ? ld4(xp + i * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  auto compute = [&](const f32x4(&xv)[XN], int gpos) {
+    const float cf = (lane < H && hact) ? A.g[(int64_t)myh * A.g_stride + gpos] : 0.f;
+#pragma unroll
+    for (int hh = 0; hh < H; ++hh) {
+      const float c = readlane_f(cf, hh);
+#pragma unroll
+      for (int i = 0; i < XN; ++i) acc[hh * XN + i] += c * xv[i];
+    }
+  };
+  for (int mbase = mb; mbase < me; mbase += 64) {
+    const int cnt = min(64, me - mbase);
+    const int ov = (lane < cnt) ? A.other[mbase + lane] : 0;
+    const int pv = (lane < cnt) ? (A.perm ? A.perm[mbase + lane] : mbase + lane) : 0;
+    load_x(xA, __builtin_amdgcn_readlane(ov, 0));
+    int i = 0;
+    for (; i + 1 < cnt; i += 2) {
+      load_x(xB, __builtin_amdgcn_readlane(ov, i + 1));
+      compute(xA, __builtin_amdgcn_readlane(pv, i));
+      if (i + 2 < cnt) load_x(xA, __builtin_amdgcn_readlane(ov, i + 2));
+      compute(xB, __builtin_amdgcn_readlane(pv, i + 1));
+    }
+    if (i < cnt) compute(xA, __builtin_amdgcn_readlane(pv, i));
+  }
+  float* op = A.gkey + (size_t)key * A.ld_gkey + xoff;
+#pragma unroll
+  for (int hh = 0; hh < H; ++hh)
+#pragma unroll
+    for (int i = 0; i < XN; ++i)
+      if (i * 256 + xoff < A.F) out4(op + hh * A.F + i * 256, acc[hh * XN + i], slot >= 0, A.accumulate != 0);
+}
+
+// gkey[key][:] (+)= sum_m sum_h coef[h][pos(m)] * Mx[other_m][h][:]
+template <int HL, int XN>
+__global__ __launch_bounds__(DISGAT_BLOCK, 2) void seg_grad_hx_col_kernel(const SegArgs A) {
+  constexpr int H = 1 << HL;
+  const int lane = threadIdx.x & 63;
+  const int item = blockIdx.x * DISGAT_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+  if (item >= A.n_items) return;
+  const int4 it = A.items[item];
+  const int key = rfl(it.x), mb = rfl(it.y), me = rfl(it.z), slot = rfl(it.w);
+  const int xoff = lane * 4;
+  const int myh = lane & (H - 1);
+  const bool hact = (myh >= A.h_lo) && (myh < A.h_hi);
+  f32x4 acc[XN], mA[H * XN], mB[H * XN];
+#pragma unroll
+  for (int i = 0; i < XN; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto load_m = [&](f32x4(&mv)[H * XN], int o) {
+    const float* mp = A.otherop + (size_t)o * A.ld_other + xoff;
+#pragma unroll
+    for (int hh = 0; hh < H; ++hh)
+      if (hh >= A.h_lo && hh < A.h_hi) {
+#pragma unroll
+        for (int i = 0; i < XN; ++i)
+          mv[hh * XN + i] = (i * 256 + xoff < A.F) ? ld4(mp + hh * A.F + i * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+  };
+  auto compute = [&](const f32x4(&mv)[H * XN], int gpos) {
+    const float cf = (lane < H && hact) ? A.g[(int64_t)myh * A.g_stride + gpos] : 0.f;
+#pragma unroll
+    for (int hh = 0; hh < H; ++hh)
+      if (hh >= A.h_lo && hh < A.h_hi) {
+        const float c = readlane_f(cf, hh);
+#pragma unroll
+        for (int i = 0; i < XN; ++i) acc[i] += c * mv[hh * XN + i];
+      }
+  };
+  for (int mbase = mb; mbase < me; mbase += 64) {
+    const int cnt = min(64, me - mbase);
+    const int ov = (lane < cnt) ? A.other[mbase + lane] : 0;
+    const int pv = (lane < cnt) ? (A.perm ? A.perm[mbase + lane] : mbase + lane) : 0;
+    load_m(mA, __builtin_amdgcn_readlane(ov, 0));
+    int i = 0;
+    for (; i + 1 < cnt; i += 2) {
+      load_m(mB, __builtin_amdgcn_readlane(ov, i + 1));
+      compute(mA, __builtin_amdgcn_readlane(pv, i));
+      if (i + 2 < cnt) load_m(mA, __builtin_amdgcn_readlane(ov, i + 2));
+      compute(mB, __builtin_amdgcn_readlane(pv, i + 1));
+    }
+    if (i < cnt) compute(mA, __builtin_amdgcn_readlane(pv, i));
+  }
+  float* op = A.gkey + (size_t)key * A.ld_gkey + xoff;
+#pragma unroll
+  for (int i = 0; i < XN; ++i)
+    if (i * 256 + xoff < A.F) out4(op + i * 256, acc[i], slot >= 0, A.accumulate != 0);
+}
+
+}  // namespace disgat
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+#include "disgat_api.h"
+
+extern "C" int disgat_bwd_alpha(const int32_t* items, int n_items, const int32_t* col, int64_t E, int H, int F_in,
+                                const float* x, int ldx, const float* gZ, const float* Z, const float* edge_e,
+                                const float* den, const float* ge_in, float* ge_out, float* beta, int sage_div,
+                                disgat_stream_t stream) {
+  using namespace disgat;
+  if (n_items == 0) return 0;
+  const int hl = ilog2_exact(H);
+  DISGAT_REQUIRE(hl >= 1 && hl <= 4, "bwd_alpha: H=%d must be a power of two in [2,16]", H);
+  DISGAT_REQUIRE(F_in > 0 && F_in % 4 == 0 && ldx % 4 == 0, "bwd_alpha: F_in/ldx must be multiples of 4");
+  DISGAT_REQUIRE(items && col && x && gZ && Z && edge_e && den && ge_out && beta, "bwd_alpha: null pointer");
+  const int xn = (F_in + 255) / 256;
+  DISGAT_REQUIRE(xn == 1 || (xn == 2 && hl <= 3), "bwd_alpha: F_in=%d too wide for H=%d", F_in, H);
+  BwdAlphaArgs A{reinterpret_cast<const int4*>(items), n_items, col, E, F_in, x, ldx, gZ, Z, edge_e, den, ge_in,
+                 ge_out, beta, sage_div};
+  const dim3 grid((n_items + DISGAT_WAVES_PER_BLOCK - 1) / DISGAT_WAVES_PER_BLOCK), block(DISGAT_BLOCK);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+#define DISGAT_BA(HL_, XN_) hipLaunchKernelGGL((bwd_alpha_kernel<HL_, XN_>), grid, block, 0, s, A)
+  if (xn == 1) {
+    switch (hl) {
+      case 1: DISGAT_BA(1, 1); break;
+      case 2: DISGAT_BA(2, 1); break;
+      case 3: DISGAT_BA(3, 1); break;
+      default: DISGAT_BA(4, 1); break;
+    }
+  } else {
+    switch (hl) {
+      case 1: DISGAT_BA(1, 2); break;
+      case 2: DISGAT_BA(2, 2); break;
+      default: DISGAT_BA(3, 2); break;
+    }
+  }
+#undef DISGAT_BA
+  return check_launch("bwd_alpha_kernel");
+}
+
+static int seg_common_checks(const char* who, const int32_t* items, int n_items, const int32_t* other, const float* g,
+                             int H, int h_lo, int h_hi, const float* otherop, float* gkey) {
+  using namespace disgat;
+  const int hl = ilog2_exact(H);
+  DISGAT_REQUIRE(hl >= 1 && hl <= 4, "%s: H=%d must be a power of two in [2,16]", who, H);
+  DISGAT_REQUIRE(h_lo >= 0 && h_hi <= H && h_lo < h_hi, "%s: bad head range [%d,%d)", who, h_lo, h_hi);
+  DISGAT_REQUIRE(items && other && g && otherop && gkey && n_items > 0, "%s: null pointer", who);
+  return 0;
+}
+
+extern "C" int disgat_seg_grad_att3(const int32_t* items, int n_items, const int32_t* other, const int32_t* perm,
+                                    const float* g, int64_t g_stride, int h_lo, int h_hi, int H, int F_out,
+                                    const float* keyop, int ld_key, const float* otherop, int ld_other, const float* a,
+                                    float* gkey, int ld_gkey, float* ga_part, int n_waves, disgat_stream_t stream) {
+  using namespace disgat;
+  if (n_items == 0) return 0;
+  if (int rc = seg_common_checks("seg_grad_att3", items, n_items, other, g, H, h_lo, h_hi, otherop, gkey)) return rc;
+  const int hl = ilog2_exact(H);
+  const int g4 = (64 >> hl) * 4;
+  DISGAT_REQUIRE(F_out > 0 && F_out % g4 == 0 && keyop && a, "seg_grad_att3: bad F_out=%d", F_out);
+  DISGAT_REQUIRE(n_waves > 0 && n_waves % DISGAT_WAVES_PER_BLOCK == 0, "seg_grad_att3: n_waves must be a positive multiple of %d", DISGAT_WAVES_PER_BLOCK);
+  const int qn = F_out / g4;
+  SegArgs A{reinterpret_cast<const int4*>(items), n_items, other, perm, g, g_stride, h_lo, h_hi, F_out, keyop, ld_key,
+            otherop, ld_other, a, gkey, ld_gkey, ga_part, 0};
+  const dim3 grid(n_waves / DISGAT_WAVES_PER_BLOCK), block(DISGAT_BLOCK);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+#define DISGAT_SG(HL_, QN_) hipLaunchKernelGGL((seg_grad_att3_kernel<HL_, QN_>), grid, block, 0, s, A)
+#define DISGAT_SGQ(HL_)                                                                       \
+  switch (qn) {                                                                               \
+    case 1: DISGAT_SG(HL_, 1); break;                                                         \
+    case 2: DISGAT_SG(HL_, 2); break;                                                         \
+    case 4: DISGAT_SG(HL_, 4); break;                                                         \
+    case 8: DISGAT_SG(HL_, 8); break;                                                         \
+    default: return fail(-2, "seg_grad_att3: F_out must be QN*(64/H)*4 with QN in {1,2,4,8}"); \
+  }
+  switch (hl) {
+    case 1: DISGAT_SGQ(1); break;
+    case 2: DISGAT_SGQ(2); break;
+    case 3: DISGAT_SGQ(3); break;
+    default: DISGAT_SGQ(4); break;
+  }
+#undef DISGAT_SGQ
+#undef DISGAT_SG
+  return check_launch("seg_grad_att3_kernel");
+}
+
+template <bool COL>
+static int launch_hx(const disgat::SegArgs& A, int hl, int xn, hipStream_t s) {
+  using namespace disgat;
+  const dim3 grid((A.n_items + DISGAT_WAVES_PER_BLOCK - 1) / DISGAT_WAVES_PER_BLOCK), block(DISGAT_BLOCK);
+#define DISGAT_HX(HL_, XN_)                                                                   \
+  do {                                                                                        \
+    if (COL) hipLaunchKernelGGL((seg_grad_hx_col_kernel<HL_, XN_>), grid, block, 0, s, A);    \
+    else hipLaunchKernelGGL((seg_grad_hx_row_kernel<HL_, XN_>), grid, block, 0, s, A);        \
+  } while (0)
+  if (xn == 1) {
+    switch (hl) {
+      case 1: DISGAT_HX(1, 1); break;
+      case 2: DISGAT_HX(2, 1); break;
+      case 3: DISGAT_HX(3, 1); break;
+      default: DISGAT_HX(4, 1); break;
+    }
+  } else if (xn == 2 && hl <= 3) {
+    switch (hl) {
+      case 1: DISGAT_HX(1, 2); break;
+      case 2: DISGAT_HX(2, 2); break;
+      default: DISGAT_HX(3, 2); break;
+    }
+  } else {
+    return fail(-2, "seg_grad_hx: F=%d too wide for H=%d", A.F, 1 << hl);
+  }
+#undef DISGAT_HX
+  return check_launch("seg_grad_hx_kernel");
+}
+
+extern "C" int disgat_seg_grad_hx(int col_mode, const int32_t* items, int n_items, const int32_t* other,
+                                  const int32_t* perm, const float* coef, int64_t coef_stride, int h_lo, int h_hi, int H,
+                                  int F, const float* otherop, int ld_other, float* gkey, int ld_gkey, int accumulate,
+                                  disgat_stream_t stream) {
+  using namespace disgat;
+  if (n_items == 0) return 0;
+  if (int rc = seg_common_checks("seg_grad_hx", items, n_items, other, coef, H, h_lo, h_hi, otherop, gkey)) return rc;
+  DISGAT_REQUIRE(F > 0 && F % 4 == 0 && ld_other % 4 == 0 && ld_gkey % 4 == 0, "seg_grad_hx: F/strides must be multiples of 4");
+  SegArgs A{reinterpret_cast<const int4*>(items), n_items, other, perm, coef, coef_stride, h_lo, h_hi, F, nullptr, 0,
+            otherop, ld_other, nullptr, gkey, ld_gkey, nullptr, accumulate};
+  const int hl = ilog2_exact(H);
+  const int xn = (F + 255) / 256;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  return col_mode ? launch_hx<true>(A, hl, xn, s) : launch_hx<false>(A, hl, xn, s);
+}

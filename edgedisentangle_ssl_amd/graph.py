@@ -24,6 +24,42 @@ class WorkItems:
     __slots__ = ("items", "n_items", "split_rows", "split_ptr", "n_split", "n_slots", "chunk")
 
 
+def build_items(ptr, chunk):
+    """Wave work items over the segments [ptr[i], ptr[i+1]): one item per segment, segments longer
+    than `chunk` cut into near-equal slices (slot >= 0), empty segments keep one empty item (their
+    output row must still be written), items ordered by descending length."""
+    dev = ptr.device
+    rp = ptr.to(torch.int64)
+    n = rp.numel() - 1
+    deg = rp[1:] - rp[:-1]
+    nchunk = torch.clamp((deg + chunk - 1) // chunk, min=1)
+    n_items = int(nchunk.sum())
+    item_row = torch.repeat_interleave(torch.arange(n, device=dev), nchunk)
+    first = torch.cumsum(nchunk, 0) - nchunk
+    j = torch.arange(n_items, device=dev) - first[item_row]
+    size = (deg // nchunk)[item_row]
+    rem = (deg % nchunk)[item_row]
+    begin = rp[:-1][item_row] + j * size + torch.minimum(j, rem)
+    end = begin + size + (j < rem).to(torch.int64)
+    is_split = (nchunk > 1)[item_row]
+    slot = torch.where(is_split, torch.cumsum(is_split.to(torch.int64), 0) - 1, torch.full_like(j, -1))
+    items = torch.stack([item_row, begin, end, slot], 1)
+    order = torch.sort(end - begin, descending=True, stable=True).indices
+    wi = WorkItems()
+    wi.items = items[order].to(torch.int32).contiguous()
+    wi.n_items = n_items
+    split_rows = torch.nonzero(nchunk > 1)[:, 0]
+    wi.n_split = int(split_rows.shape[0])
+    wi.split_rows = split_rows.to(torch.int32).contiguous()
+    sp = torch.zeros(wi.n_split + 1, dtype=torch.int64, device=dev)
+    if wi.n_split:
+        sp[1:] = torch.cumsum(nchunk[split_rows], 0)
+    wi.split_ptr = sp.to(torch.int32).contiguous()
+    wi.n_slots = int(sp[-1])
+    wi.chunk = chunk
+    return wi
+
+
 class CSRGraph:
     def __init__(self, n, rowptr, col, row):
         self.n = int(n)
@@ -66,38 +102,9 @@ class CSRGraph:
     # ------------------------------------------------------------------ work items
     def work_items(self, chunk):
         wi = self._items.get(chunk)
-        if wi is not None:
-            return wi
-        dev = self.device
-        n = self.n
-        rp = self.rowptr.to(torch.int64)
-        deg = rp[1:] - rp[:-1]
-        nchunk = torch.clamp((deg + chunk - 1) // chunk, min=1)
-        n_items = int(nchunk.sum())
-        item_row = torch.repeat_interleave(torch.arange(n, device=dev), nchunk)
-        first = torch.cumsum(nchunk, 0) - nchunk
-        j = torch.arange(n_items, device=dev) - first[item_row]
-        size = (deg // nchunk)[item_row]
-        rem = (deg % nchunk)[item_row]
-        begin = rp[:-1][item_row] + j * size + torch.minimum(j, rem)
-        end = begin + size + (j < rem).to(torch.int64)
-        is_split = (nchunk > 1)[item_row]
-        slot = torch.where(is_split, torch.cumsum(is_split.to(torch.int64), 0) - 1, torch.full_like(j, -1))
-        items = torch.stack([item_row, begin, end, slot], 1)
-        order = torch.sort(end - begin, descending=True, stable=True).indices
-        wi = WorkItems()
-        wi.items = items[order].to(torch.int32).contiguous()
-        wi.n_items = n_items
-        split_rows = torch.nonzero(nchunk > 1)[:, 0]
-        wi.n_split = int(split_rows.shape[0])
-        wi.split_rows = split_rows.to(torch.int32).contiguous()
-        sp = torch.zeros(wi.n_split + 1, dtype=torch.int64, device=dev)
-        if wi.n_split:
-            sp[1:] = torch.cumsum(nchunk[split_rows], 0)
-        wi.split_ptr = sp.to(torch.int32).contiguous()
-        wi.n_slots = int(sp[-1])
-        wi.chunk = chunk
-        self._items[chunk] = wi
+        if wi is None:
+            wi = build_items(self.rowptr, chunk)
+            self._items[chunk] = wi
         return wi
 
     # ------------------------------------------------------------------ transpose (for backward)

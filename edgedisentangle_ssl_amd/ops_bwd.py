@@ -1,0 +1,124 @@
+"""Host orchestration of the backward passes (csrc/edge_bwd.hip) for ops.EdgePass / ops.AuxPass."""
+import torch
+
+from . import _lib, ops
+from .graph import build_items
+
+_MAX_WAVES = 8192      # persistent seg_grad_att3 launch: 2048 blocks x 4 waves
+
+
+def _buf(shape, dev, zero):
+    return (torch.zeros if zero else torch.empty)(shape, dtype=torch.float32, device=dev)
+
+
+def _seg_att3(wi, other, perm, g, lo, hi, H, f_out, keyop, otherop, a, n_keys, want_ga):
+    dev = g.device
+    gkey = _buf((n_keys, H * f_out), dev, wi.n_split > 0)
+    n_waves = min(_MAX_WAVES, (wi.n_items + 3) // 4 * 4)
+    ga_part = torch.empty((n_waves, H * f_out), dtype=torch.float32, device=dev) if want_ga else None
+    _lib.call("disgat_seg_grad_att3", wi.items.data_ptr(), wi.n_items, other.data_ptr(), ops._ptr(perm), g.data_ptr(),
+              g.stride(0), lo, hi, H, f_out, keyop.data_ptr(), keyop.stride(0), otherop.data_ptr(), otherop.stride(0),
+              a.data_ptr(), gkey.data_ptr(), gkey.stride(0), ops._ptr(ga_part), n_waves, ops._stream())
+    return gkey, (ga_part.sum(0) if want_ga else None)
+
+
+def _seg_hx(col_mode, wi, other, perm, coef, lo, hi, H, f, otherop, gkey, accumulate):
+    _lib.call("disgat_seg_grad_hx", int(col_mode), wi.items.data_ptr(), wi.n_items, other.data_ptr(), ops._ptr(perm),
+              coef.data_ptr(), coef.stride(0), lo, hi, H, f, otherop.data_ptr(), otherop.stride(0), gkey.data_ptr(),
+              gkey.stride(0), int(accumulate), ops._stream())
+
+
+def edge_backward(ctx, gz, ge):
+    x, rowop, colop, a, z, edge_e, den = ctx.saved_tensors
+    graph, att, H, f_in, f_out, sage = ctx.cfg
+    need_x, need_row, need_col, need_a = ctx.needs_input_grad[:4]
+    dev = x.device
+    n, e = graph.n, graph.nnz
+    chunk = ops.CHUNK[att]
+    wi = graph.work_items(chunk)
+    gz = torch.zeros_like(z) if gz is None else gz.contiguous()
+    ge = None if ge is None else ge.contiguous()
+    ge_tot = torch.empty((H, e), dtype=torch.float32, device=dev)
+    beta = torch.empty((H, e), dtype=torch.float32, device=dev)
+    _lib.call("disgat_bwd_alpha", wi.items.data_ptr(), wi.n_items, graph.col.data_ptr(), e, H, f_in, x.data_ptr(),
+              x.stride(0), gz.data_ptr(), z.data_ptr(), edge_e.data_ptr(), den.data_ptr(), ops._ptr(ge), ge_tot.data_ptr(),
+              beta.data_ptr(), int(bool(sage)), ops._stream())
+    g_x = g_row = g_col = g_a = None
+    t = twi = None
+    if need_x or (att == 3 and need_col):
+        t = graph.transpose()
+        twi = t.work_items(chunk)
+    if att == 1:
+        if need_row:
+            g_row = torch.zeros((n, H), dtype=torch.float32, device=dev).index_add_(0, graph.row, ge_tot.t())
+        if need_col:
+            g_col = torch.zeros((colop.shape[0], H), dtype=torch.float32, device=dev).index_add_(
+                0, graph.col.long(), ge_tot.t())
+    elif att == 2:
+        if need_row:                                    # gP[r,h,:] = sum_k ge_k x[col_k]
+            g_row = _buf((n, H * f_in), dev, wi.n_split > 0)
+            _seg_hx(0, wi, graph.col, None, ge_tot, 0, H, H, f_in, x, g_row, False)
+    else:
+        if need_row or need_a:
+            g_row, g_a = _seg_att3(wi, graph.col, None, ge_tot, 0, H, H, f_out, rowop, colop, a, n, need_a)
+        if need_col:
+            g_col, _ = _seg_att3(twi, t.col, t.eid, ge_tot, 0, H, H, f_out, colop, rowop, a, colop.shape[0], False)
+    if need_x:
+        g_x = _buf(tuple(x.shape), dev, twi.n_split > 0 or x.stride(0) != f_in)
+        # grad of the aggregation: gx[c] = sum_{k in col c} sum_h beta_kh gZ[row_k,h,:]
+        _seg_hx(1, twi, t.col, t.eid, beta, 0, H, H, f_in, gz.view(n, H * f_in), g_x, False)
+        if att == 2:                                    # e = <P[r,h,:], x[c,:]>  ->  gx[c] += sum_h ge_kh P[r_k,h,:]
+            _seg_hx(1, twi, t.col, t.eid, ge_tot, 0, H, H, f_in, rowop, g_x, True)
+    return g_x, g_row, g_col, g_a, None
+
+
+def _segments(keys, n_keys, chunk):
+    """Work items over a key-sorted list + the int32 permutation that sorts it (None if sorted)."""
+    m = keys.numel()
+    if m > 1 and not bool((keys[1:] >= keys[:-1]).all()):
+        perm = torch.sort(keys, stable=True).indices
+        keys = keys[perm]
+        perm32 = perm.to(torch.int32)
+    else:
+        perm, perm32 = None, None
+    ptr = torch.searchsorted(keys, torch.arange(n_keys + 1, device=keys.device, dtype=keys.dtype))
+    return build_items(ptr, chunk), perm, perm32
+
+
+def aux_backward(ctx, gout):
+    x, rowop, colop, a, pairs = ctx.saved_tensors
+    att, H, f_in, f_out, n, lo, hi = ctx.cfg
+    need_x, need_row, need_col, need_a = ctx.needs_input_grad[:4]
+    dev = gout.device
+    gout = gout.contiguous()
+    rows, cols = pairs[0], pairs[1]
+    g_x = g_row = g_col = g_a = None
+    if att == 1:
+        gsub = gout[lo:hi].t()
+        if need_row:
+            g_row = torch.zeros_like(rowop)
+            g_row[:, lo:hi] = torch.zeros((rowop.shape[0], hi - lo), dtype=torch.float32, device=dev).index_add_(0, rows, gsub)
+        if need_col:
+            g_col = torch.zeros_like(colop)
+            g_col[:, lo:hi] = torch.zeros((colop.shape[0], hi - lo), dtype=torch.float32, device=dev).index_add_(0, cols, gsub)
+        return g_x, g_row, g_col, g_a, None, None
+    chunk = ops.CHUNK[att]
+    n_rows = rowop.shape[0]
+    n_cols = colop.shape[0] if att == 3 else x.shape[0]
+    if need_row or need_a:
+        wi, perm, perm32 = _segments(rows, n_rows, chunk)
+        other = (cols if perm is None else cols[perm]).to(torch.int32)
+        if att == 3:
+            g_row, g_a = _seg_att3(wi, other, perm32, gout, lo, hi, H, f_out, rowop, colop, a, n_rows, need_a)
+        else:
+            g_row = _buf((n_rows, H * f_in), dev, wi.n_split > 0)
+            _seg_hx(0, wi, other, perm32, gout, lo, hi, H, f_in, x, g_row, False)
+    if (att == 3 and need_col) or (att == 2 and need_x):
+        wi, perm, perm32 = _segments(cols, n_cols, chunk)
+        other = (rows if perm is None else rows[perm]).to(torch.int32)
+        if att == 3:
+            g_col, _ = _seg_att3(wi, other, perm32, gout, lo, hi, H, f_out, colop, rowop, a, n_cols, False)
+        else:
+            g_x = _buf(tuple(x.shape), dev, wi.n_split > 0 or x.stride(0) != f_in)
+            _seg_hx(1, wi, other, perm32, gout, lo, hi, H, f_in, rowop, g_x, False)
+    return g_x, g_row, g_col, g_a, None, None

@@ -20,8 +20,9 @@
  *                       reference counterpart: load balancing for power-law rows).
  *  disgat_aux_score     the auxiliary node-pair scoring of predict_adjs_sparse
  *                       (layers.py:355-360, 368-372, 381-389; models.py:290-330).
- *  disgat_edge_bwd_*    autograd of the above (the reference relies on ATen autograd of
- *                       index/cat/mm/scatter_add_; loss.backward() at pretrainer.py:752).
+ *  disgat_bwd_alpha,    autograd of the above: the reference relies on ATen autograd through
+ *  disgat_seg_grad_*    index / cat / mm / scatter_add_ (loss.backward() at pretrainer.py:752, 631,
+ *                       836; trainer.py:200).  Gather-only segment passes, see csrc/edge_bwd.hip.
  *  disgat_pair_loss     sigmoid(sum of heads) + utils.adj_mse_loss partial sums
  *                       (pretrainer.py:727-739, 612-627; utils.py:287-298).
  *
@@ -88,6 +89,34 @@ int disgat_aux_score(int att, const int64_t* pair_rows, const int64_t* pair_cols
  * acc (3 doubles) must be zeroed by the caller. */
 int disgat_pair_loss(const float* aux, int64_t M, int h_lo, int h_hi, const float* labels,
                      double* acc, disgat_stream_t stream);
+
+/* ---- backward -------------------------------------------------------------------------- */
+
+/* Per edge and head: ge_out = ge_in + d(loss)/d(e) through softmax-of-sigmoid given gZ (grad of Z),
+ * and beta = alpha*sc, the coefficient of x[col] in Z (used by the transposed pass for grad x).
+ * ge_in may be NULL.  Items/col as in disgat_edge_fwd; Z, den, edge_e are the forward's outputs. */
+int disgat_bwd_alpha(const int32_t* items, int n_items, const int32_t* col, int64_t E, int H, int F_in,
+                     const float* x, int ldx, const float* gZ, const float* Z, const float* edge_e,
+                     const float* den, const float* ge_in, float* ge_out, float* beta, int sage_div,
+                     disgat_stream_t stream);
+
+/* Segment gradient of the att-3 score e = sum_f a_f lrelu(keyop[key] + otherop[other]).
+ * items = {key, m_begin, m_end, slot} over a list sorted by key; other[m] = gathered node of list
+ * position m; perm[m] (or NULL = identity) = column of g holding that position's upstream grad.
+ * gkey[key] = sum_m g*a*lrelu'(z) (plain store, or atomic add into host-zeroed rows when slot >= 0);
+ * ga_part (or NULL): [n_waves][H*F_out] per-wave partial sums of g*lrelu(z) (sum them on the host).
+ * n_waves: multiple of 4; the launch is persistent (grid-stride over items). */
+int disgat_seg_grad_att3(const int32_t* items, int n_items, const int32_t* other, const int32_t* perm,
+                         const float* g, int64_t g_stride, int h_lo, int h_hi, int H, int F_out,
+                         const float* keyop, int ld_key, const float* otherop, int ld_other, const float* a,
+                         float* gkey, int ld_gkey, float* ga_part, int n_waves, disgat_stream_t stream);
+
+/* col_mode = 0: gkey[key][h][:] = sum_m coef[h][perm(m)] * otherop[other_m][:]          (F floats per row)
+ * col_mode = 1: gkey[key][:] (+)= sum_m sum_h coef[h][perm(m)] * otherop[other_m][h][:]  (otherop rows H*F) */
+int disgat_seg_grad_hx(int col_mode, const int32_t* items, int n_items, const int32_t* other,
+                       const int32_t* perm, const float* coef, int64_t coef_stride, int h_lo, int h_hi, int H,
+                       int F, const float* otherop, int ld_other, float* gkey, int ld_gkey, int accumulate,
+                       disgat_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,129 @@
+"""GPU parity of the backward passes: parameter gradients of the three SSL losses against the
+golden gradients recorded from the unmodified reference (tiny graph, all 9 combos), and against
+the CPU oracle's autograd on Cora (split segments forced on)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import inputs_common as ic
+from test_gpu_parity import GNNS, ATTS, build, close, dev, make_args, real_inputs, tiny_inputs  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+GTOL = 2e-4
+
+
+def _trainers(a, enc, seed, devc):
+    from edgedisentangle_ssl_amd import pretrainer
+    a.lr, a.weight_decay, a.dis_type = 0.01, 5e-4, 1
+    out = []
+    for cls in (pretrainer.SupEdgeTrainer, pretrainer.GeneratedEdgeTrainer, pretrainer.DifHeadTrainer):
+        tr = cls(a, enc, 1.0)
+        ic.load_params(tr.fuse1, seed + 1)
+        ic.load_params(tr.fuse2, seed + 2)
+        out.append(tr)
+    ic.load_params(out[2].classifier1, seed + 4)
+    ic.load_params(out[2].classifier2, seed + 5)
+    for tr in out:
+        for m in tr.models:
+            m.to(devc).eval()
+    return out
+
+
+def _zero(enc):
+    for p in enc.parameters():
+        p.grad = None
+
+
+def _check(enc, g, prefix, tol=GTOL):
+    for k, p in enc.named_parameters():
+        if k.startswith(("fuser1", "fuser2")):
+            continue
+        got = p.grad if p.grad is not None else torch.zeros_like(p)
+        close(got, g[f"{prefix}.{k}"], tol=tol, what=f"{prefix}.{k}")
+
+
+@pytest.mark.parametrize("chunk", [None, 8])
+@pytest.mark.parametrize("gnn", GNNS)
+@pytest.mark.parametrize("att", ATTS)
+def test_tiny_loss_gradients(golden_dir, dev, gnn, att, chunk, monkeypatch):
+    from edgedisentangle_ssl_amd import ops
+    if chunk is not None:
+        monkeypatch.setattr(ops, "CHUNK", {1: chunk, 2: chunk, 3: chunk})
+    g = np.load(os.path.join(golden_dir, f"tiny_{gnn}_att{att}.npz"))
+    x, adj, n, aux = tiny_inputs(dev)
+    idx, _, _ = ic.tiny_graph()
+    ci = ic.coalesced_index_set(idx, n)
+    labels = torch.from_numpy(np.random.Generator(np.random.PCG64(3)).integers(0, 3, n))
+    pos, homo, het = ic.edge_sets(ci, labels, n)
+    sup = ic.sample_pairs(31, n, pos, "sup")
+    ho = ic.sample_pairs(32, n, homo, "homo")
+    he = ic.sample_pairs(33, n, het, "het")
+    seed = 100 + att
+    a, enc, _ = build(gnn, att, 4, 16, 16, seed, dev)
+    sup_t, dis_t, dif_t = _trainers(a, enc, seed, dev)
+    data = (x, adj)
+
+    _zero(enc)
+    loss = sup_t.loss(data, sup[1].to(dev), [sup[0].to(dev)])
+    close(loss, g["loss_sup"], tol=1e-5, what="loss_sup")
+    loss.backward()
+    _check(enc, g, "gsup.enc")
+    for k, p in sup_t.fuse1.named_parameters():
+        close(p.grad, g[f"gsup.fuse1.{k}"], tol=GTOL, what=f"gsup.fuse1.{k}")
+
+    _zero(enc)
+    loss = dis_t.loss(data, [ho[1].to(dev), he[1].to(dev)], [ho[0].to(dev), he[0].to(dev)])
+    close(loss, g["loss_dis"], tol=1e-5, what="loss_dis")
+    loss.backward()
+    _check(enc, g, "gdis.enc")
+
+    _zero(enc)
+    loss = dif_t.loss(data)
+    close(loss, g["loss_dif"], tol=1e-5, what="loss_dif")
+    loss.backward()
+    _check(enc, g, "gdif.enc")
+    for k, p in dif_t.classifier1.named_parameters():
+        close(p.grad, g[f"gdif.cls1.{k}"], tol=GTOL, what=f"gdif.cls1.{k}")
+
+
+@pytest.mark.parametrize("gnn,att", [("AT", 3), ("SAGE", 2), ("GCN", 1), ("AT", 2), ("SAGE", 3)])
+def test_cora_gradients_vs_oracle_autograd(golden_dir, dev, gnn, att, monkeypatch):
+    """Cora (H=8, nhid=64): d(SupEdge+DisEdge loss)/d(params) and d/d(input features) against the CPU
+    oracle's autograd in float64 (arbiter), chunk 32 so hub rows/columns take the split path."""
+    from edgedisentangle_ssl_amd import ops
+    from oracle import disgat_oracle as orc
+    from test_oracle_golden import shapes_disgat, shapes_fuser
+    monkeypatch.setattr(ops, "CHUNK", {1: 32, 2: 32, 3: 32})
+    x, adj, n, ei, sup, ho, he = real_inputs(golden_dir, "cora", dev)
+    # thin the pair lists (unsorted on purpose: exercises the sort path of aux_backward)
+    rp = torch.randperm(sup[0].shape[1], generator=torch.Generator().manual_seed(1))[:6000]
+    sidx, slab = sup[0][:, rp], sup[1][rp]
+    seed = 200 + att
+    a, enc, _ = build(gnn, att, 8, 64, x.shape[1], seed, dev)
+    sup_t, dis_t, _ = _trainers(a, enc, seed, dev)
+    xg = x.clone().requires_grad_(True)
+    loss = sup_t.loss((xg, adj), slab.to(dev), [sidx.to(dev)]) + \
+        dis_t.loss((xg, adj), [ho[1].to(dev), he[1].to(dev)], [ho[0].to(dev), he[0].to(dev)])
+    _zero(enc)
+    loss.backward()
+
+    sd = {k: v.double().requires_grad_(True) for k, v in ic.make_params(shapes_disgat(gnn, att, x.shape[1], 64, 8), seed).items()}
+    fus = []
+    for k in (1, 2):
+        p = {kk: vv.double() for kk, vv in ic.make_params(shapes_fuser(64, 8), seed + k).items()}
+        fus.append(lambda heads, res, p=p: orc.fuse_layer(p, heads, res))
+    xc = x.detach().cpu().double().requires_grad_(True)
+    r1 = orc.disgat_pass(sd, xc, ei, fus, 8, att, gnn, [sidx])
+    r2 = orc.disgat_pass(sd, xc, ei, fus, 8, att, gnn, [ho[0], he[0]])
+    ref = orc.sup_edge_loss(r1["aux"], slab.double()) + orc.dis_edge_loss(r2["aux"], ho[1].double(), he[1].double())
+    ref.backward()
+    close(loss, ref.detach(), tol=1e-5, what="loss")
+    close(xg.grad, xc.grad, tol=GTOL, what="grad x")
+    for k, p in enc.named_parameters():
+        if k.startswith(("fuser1", "fuser2")):
+            continue
+        want = sd[k].grad if sd[k].grad is not None else torch.zeros_like(sd[k])
+        got = p.grad if p.grad is not None else torch.zeros_like(p)
+        close(got, want, tol=GTOL, what=f"grad {k}")
