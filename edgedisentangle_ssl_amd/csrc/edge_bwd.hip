@@ -48,11 +48,12 @@ struct BwdAlphaArgs {
   const float* gZ;      // [N][H][F_in]
   const float* Z;       // [N][H][F_in]
   const float* edge_e;  // [H][E]
-  const float* den;     // [N][H]
+  const float* den;     // [N][2][H]: softmax denominators, dropped-out numerator sums
   const float* ge_in;   // [H][E] or null
   float* ge_out;        // [H][E]
   float* beta;          // [H][E]
   int sage_div;
+  DropCfg drop;
 };
 
 template <int HL, int XN>
@@ -87,9 +88,10 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void bwd_alpha_kernel(const BwdAlp
       tsel = (myh == hh) ? acc : tsel;
     }
   }
-  const float den = A.den[(size_t)row * H + myh];
+  const float den = A.den[(size_t)row * (2 * H) + myh];
+  const float dsum = A.den[(size_t)row * (2 * H) + H + myh];
   const float inv = (den > 0.f) ? 1.0f / den : 0.f;
-  const float scs = A.sage_div ? 1.0f / (den * inv + 1.0f) : 1.0f;
+  const float scs = A.sage_div ? 1.0f / (dsum * inv + 1.0f) : 1.0f;
 
   f32x4 xA[XN], xB[XN];
   auto load_x = [&](f32x4(&xv)[XN], int c) {
@@ -112,11 +114,12 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void bwd_alpha_kernel(const BwdAlp
       const float e = A.edge_e[o];
       const float s = sigmoidf_(e);
       const float alpha = expf(s) * inv;
-      const float gs = alpha * (scs * gal - tsel);
+      const float cf = scs * drop_mult(A.drop, k, myh, H);   // Z = sum_k alpha_k * cf_k * x[col_k]
+      const float gs = alpha * (cf * gal - tsel);
       float g = gs * s * (1.0f - s);
       if (A.ge_in != nullptr) g += A.ge_in[o];
       A.ge_out[o] = g;
-      A.beta[o] = alpha * scs;
+      A.beta[o] = alpha * cf;
     }
   };
   for (int kbase = kb; kbase < ke; kbase += 64) {
@@ -348,7 +351,7 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void seg_grad_hx_col_kernel(const 
 extern "C" int disgat_bwd_alpha(const int32_t* items, int n_items, const int32_t* col, int64_t E, int H, int F_in,
                                 const float* x, int ldx, const float* gZ, const float* Z, const float* edge_e,
                                 const float* den, const float* ge_in, float* ge_out, float* beta, int sage_div,
-                                disgat_stream_t stream) {
+                                float drop_p, uint64_t drop_seed, disgat_stream_t stream) {
   using namespace disgat;
   if (n_items == 0) return 0;
   const int hl = ilog2_exact(H);
@@ -358,7 +361,8 @@ extern "C" int disgat_bwd_alpha(const int32_t* items, int n_items, const int32_t
   const int xn = (F_in + 255) / 256;
   DISGAT_REQUIRE(xn == 1 || (xn == 2 && hl <= 3), "bwd_alpha: F_in=%d too wide for H=%d", F_in, H);
   BwdAlphaArgs A{reinterpret_cast<const int4*>(items), n_items, col, E, F_in, x, ldx, gZ, Z, edge_e, den, ge_in,
-                 ge_out, beta, sage_div};
+                 ge_out, beta, sage_div,
+                 DropCfg{drop_seed, (uint32_t)((double)drop_p * 4294967296.0), 1.0f / (1.0f - drop_p)}};
   const dim3 grid((n_items + DISGAT_WAVES_PER_BLOCK - 1) / DISGAT_WAVES_PER_BLOCK), block(DISGAT_BLOCK);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 #define DISGAT_BA(HL_, XN_) hipLaunchKernelGGL((bwd_alpha_kernel<HL_, XN_>), grid, block, 0, s, A)

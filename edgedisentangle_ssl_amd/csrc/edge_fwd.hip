@@ -41,6 +41,7 @@ struct EdgeFwdArgs {
   float* part_z;
   float* part_den;
   int sage_div;
+  DropCfg drop;
 };
 
 template <int ATT, int HL, int QN, int XN>
@@ -95,7 +96,8 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void edge_fwd_kernel(const EdgeFwd
   f32x4 zacc[H * XN];
 #pragma unroll
   for (int i = 0; i < H * XN; ++i) zacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float den = 0.f;
+  float den = 0.f;   // softmax denominator: every edge
+  float dsum = 0.f;  // sum of the dropped-out numerator weights (== den without dropout)
 
   using Buf = ColBuf<ATT, HL, QN, XN>;
 
@@ -138,9 +140,11 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void edge_fwd_kernel(const EdgeFwd
     }
     const float w = softmax_num(e);
     den += w;
+    const float wd = w * drop_mult(A.drop, k, myh, H);
+    dsum += wd;
 #pragma unroll
     for (int hh = 0; hh < H; ++hh) {
-      const float wh = readlane_f(w, head_lane(hh));
+      const float wh = readlane_f(wd, head_lane(hh));
 #pragma unroll
       for (int i = 0; i < XN; ++i) zacc[hh * XN + i] += wh * b.xv[i];
     }
@@ -165,8 +169,9 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void edge_fwd_kernel(const EdgeFwd
   // ---- epilogue
   if (slot < 0) {
     float inv = (den > 0.f) ? 1.0f / den : 0.f;
-    // SageConv divides the aggregate by rowsum(attention)+1 (layers.py:103); rowsum = den*inv
-    if (A.sage_div) inv = inv / (den * inv + 1.0f);
+    // SageConv divides the aggregate by rowsum(attention)+1 (layers.py:103), attention taken AFTER
+    // dropout (layers.py:394, 402): rowsum = dsum*inv
+    if (A.sage_div) inv = inv / (dsum * inv + 1.0f);
     float* zp = A.Z + (size_t)row * (H * A.F_in) + xoff;
 #pragma unroll
     for (int hh = 0; hh < H; ++hh) {
@@ -175,7 +180,10 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void edge_fwd_kernel(const EdgeFwd
       for (int i = 0; i < XN; ++i)
         if (i * 256 + xoff < A.F_in) st4(zp + hh * A.F_in + i * 256, zacc[hh * XN + i] * sc);
     }
-    if (A.den != nullptr && ((ATT == 3) ? ((lane & (G - 1)) == 0) : (lane < H))) A.den[(size_t)row * H + myh] = den;
+    if (A.den != nullptr && ((ATT == 3) ? ((lane & (G - 1)) == 0) : (lane < H))) {
+      A.den[(size_t)row * (2 * H) + myh] = den;
+      A.den[(size_t)row * (2 * H) + H + myh] = dsum;
+    }
   } else {
     float* zp = A.part_z + (size_t)slot * (H * A.F_in) + xoff;
 #pragma unroll
@@ -183,7 +191,10 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void edge_fwd_kernel(const EdgeFwd
 #pragma unroll
       for (int i = 0; i < XN; ++i)
         if (i * 256 + xoff < A.F_in) st4(zp + hh * A.F_in + i * 256, zacc[hh * XN + i]);
-    if ((ATT == 3) ? ((lane & (G - 1)) == 0) : (lane < H)) A.part_den[(size_t)slot * H + myh] = den;
+    if ((ATT == 3) ? ((lane & (G - 1)) == 0) : (lane < H)) {
+      A.part_den[(size_t)slot * (2 * H) + myh] = den;
+      A.part_den[(size_t)slot * (2 * H) + H + myh] = dsum;
+    }
   }
 }
 
@@ -199,16 +210,20 @@ __global__ __launch_bounds__(256) void edge_combine_kernel(const int32_t* __rest
   const int HF = H * F_in;
   for (int idx = threadIdx.x * 4; idx < HF; idx += 256 * 4) {
     const int h = idx / F_in;
-    float den = 0.f;
+    float den = 0.f, dsum = 0.f;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     for (int sl = s0; sl < s1; ++sl) {
-      den += part_den[(size_t)sl * H + h];
+      den += part_den[(size_t)sl * (2 * H) + h];
+      dsum += part_den[(size_t)sl * (2 * H) + H + h];
       acc += ld4(part_z + (size_t)sl * HF + idx);
     }
     float inv = (den > 0.f) ? 1.0f / den : 0.f;
-    if (sage_div) inv = inv / (den * inv + 1.0f);
+    if (sage_div) inv = inv / (dsum * inv + 1.0f);
     st4(Z + (size_t)row * HF + idx, acc * inv);
-    if (den_out != nullptr && idx % F_in == 0) den_out[(size_t)row * H + h] = den;
+    if (den_out != nullptr && idx % F_in == 0) {
+      den_out[(size_t)row * (2 * H) + h] = den;
+      den_out[(size_t)row * (2 * H) + H + h] = dsum;
+    }
   }
 }
 
@@ -267,9 +282,11 @@ static int launch_edge_h(int hl, int qn, int xn, const EdgeFwdArgs& args, hipStr
 extern "C" int disgat_edge_fwd(int att, const int32_t* items, int n_items, const int32_t* col, int64_t E, int N, int H,
                                int F_in, int F_out, const float* x, int ldx, const float* rowop, int ld_row,
                                const float* colop, int ld_col, const float* a, float* Z, float* edge_e, float* den,
-                               float* part_z, float* part_den, int sage_div, disgat_stream_t stream) {
+                               float* part_z, float* part_den, int sage_div, float drop_p, uint64_t drop_seed,
+                               disgat_stream_t stream) {
   using namespace disgat;
   DISGAT_REQUIRE(att >= 1 && att <= 3, "edge_fwd: att=%d not in 1..3", att);
+  DISGAT_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "edge_fwd: dropout p=%f outside [0,1)", (double)drop_p);
   DISGAT_REQUIRE(n_items >= 0 && N > 0 && E >= 0, "edge_fwd: bad sizes n_items=%d N=%d E=%lld", n_items, N, (long long)E);
   if (n_items == 0) return 0;
   const int hl = ilog2_exact(H);
@@ -292,7 +309,8 @@ extern "C" int disgat_edge_fwd(int att, const int32_t* items, int n_items, const
     DISGAT_REQUIRE(colop && ld_row >= H && ld_col >= H, "edge_fwd att=1: bad s1/s2");
   }
   EdgeFwdArgs args{reinterpret_cast<const int4*>(items), n_items, col, E, N, F_in, x, ldx, rowop, ld_row, colop, ld_col,
-                   a, Z, edge_e, den, part_z, part_den, sage_div};
+                   a, Z, edge_e, den, part_z, part_den, sage_div,
+                   DropCfg{drop_seed, (uint32_t)((double)drop_p * 4294967296.0), 1.0f / (1.0f - drop_p)}};
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   switch (att) {
     case 1: return launch_edge_h<1>(hl, qn, xn, args, s);

@@ -170,9 +170,11 @@ def disga_heads(layers, x, adj, aux_indices=None, head_ranges=None):
         raise ValueError(f"expected a 2-D [N,{f_in}] input (layers.py:475 asserts 2-D), got {tuple(x.shape)}")
     if not x.is_cuda:
         raise RuntimeError("DISGAT HIP path: input must live on the GPU; there is no CPU fallback")
+    drop = (0.0, 0)
     if l0.training and l0.dropout > 0:
-        # attention dropout (layers.py:394) is not fused yet: refuse rather than silently skip it
-        raise NotImplementedError("attention dropout > 0 in training mode is not built yet; use --dropout 0 or eval()")
+        # attention dropout (layers.py:394) is generated inside the kernel from a counter-based hash;
+        # the seed comes from torch's CPU generator, so torch.manual_seed makes runs repeatable.
+        drop = (float(l0.dropout), int(torch.randint(0, 2 ** 62, (1,)).item()))
     graph = graph_of(adj)
     if graph.n != x.shape[0]:
         raise ValueError("adjacency / feature row count mismatch")
@@ -186,7 +188,7 @@ def disga_heads(layers, x, adj, aux_indices=None, head_ranges=None):
     xg = x_all if (f_in_p == f_in and x_all.is_contiguous()) else F.pad(x_all, (0, f_in_p - f_in)).contiguous()
 
     rowop, colop, a_vec, f_out_p = _pack_score_operands(layers, x, x_all, att, H, Hp, f_in, f_out)
-    cfg = (graph, att, Hp, f_in_p, f_out_p, gnn == "SAGE")
+    cfg = (graph, att, Hp, f_in_p, f_out_p, gnn == "SAGE", drop)
     z, edge_e, _den = ops.EdgePass.apply(xg, rowop, colop, a_vec, cfg)
 
     # ---- per-head output projection on the aggregated neighbourhood (dense, MFMA)

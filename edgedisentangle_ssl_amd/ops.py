@@ -66,11 +66,12 @@ def _row_major(t, name):
     return t
 
 
-def edge_forward(graph: CSRGraph, att, H, F_in, F_out, x, rowop, colop, a, sage_div, need_den=True):
+def edge_forward(graph: CSRGraph, att, H, F_in, F_out, x, rowop, colop, a, sage_div, drop=(0.0, 0), need_den=True):
     """Launch disgat_edge_fwd (+ disgat_edge_combine for split rows).
 
     x [N, >=F_in] (row stride % 4 == 0), rowop/colop 2-D views with unit inner
-    stride, a [H*F_out] or None.  Returns Z [N,H,F_in], edge_e [H,E], den [N,H].
+    stride, a [H*F_out] or None; drop = (p, seed) of the attention dropout.  Returns Z [N,H,F_in],
+    edge_e [H,E], den [N,2,H].
     """
     for t, nm in ((x, "x"), (rowop, "rowop")) + (((colop, "colop"),) if colop is not None else ()):
         _check(t, nm)
@@ -80,16 +81,17 @@ def edge_forward(graph: CSRGraph, att, H, F_in, F_out, x, rowop, colop, a, sage_
     wi = graph.work_items(CHUNK[att])
     z = torch.empty((n, H, F_in), dtype=torch.float32, device=dev)
     edge_e = torch.empty((H, e), dtype=torch.float32, device=dev)
-    den = torch.empty((n, H), dtype=torch.float32, device=dev) if need_den else None
+    den = torch.empty((n, 2, H), dtype=torch.float32, device=dev) if need_den else None
     part_z = part_den = None
     if wi.n_slots:
         part_z = torch.empty((wi.n_slots, H, F_in), dtype=torch.float32, device=dev)
-        part_den = torch.empty((wi.n_slots, H), dtype=torch.float32, device=dev)
+        part_den = torch.empty((wi.n_slots, 2, H), dtype=torch.float32, device=dev)
     st = _stream()
     _launch("disgat_edge_fwd", f"edge_fwd_att{att}", edge_algorithmic_bytes(att, n, e, H, F_in, F_out),
             att, _ptr(wi.items), wi.n_items, _ptr(graph.col), e, n, H, F_in, F_out,
               _ptr(x), x.stride(0), _ptr(rowop), rowop.stride(0), _ptr(colop), 0 if colop is None else colop.stride(0),
-              _ptr(a), _ptr(z), _ptr(edge_e), _ptr(den), _ptr(part_z), _ptr(part_den), int(bool(sage_div)), st)
+              _ptr(a), _ptr(z), _ptr(edge_e), _ptr(den), _ptr(part_z), _ptr(part_den), int(bool(sage_div)),
+              float(drop[0]), int(drop[1]), st)
     if wi.n_split:
         _lib.call("disgat_edge_combine", _ptr(wi.split_rows), _ptr(wi.split_ptr), wi.n_split, H, F_in,
                   _ptr(part_z), _ptr(part_den), _ptr(z), _ptr(den), int(bool(sage_div)), st)
@@ -128,8 +130,8 @@ class EdgePass(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, rowop, colop, a, cfg):
-        graph, att, H, F_in, F_out, sage = cfg
-        z, edge_e, den = edge_forward(graph, att, H, F_in, F_out, x, rowop, colop, a, sage)
+        graph, att, H, F_in, F_out, sage, drop = cfg
+        z, edge_e, den = edge_forward(graph, att, H, F_in, F_out, x, rowop, colop, a, sage, drop)
         ctx.cfg = cfg
         ctx.save_for_backward(x, rowop, colop, a, z, edge_e, den)
         ctx.mark_non_differentiable(den)

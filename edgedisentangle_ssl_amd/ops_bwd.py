@@ -30,7 +30,7 @@ def _seg_hx(col_mode, wi, other, perm, coef, lo, hi, H, f, otherop, gkey, accumu
 
 def edge_backward(ctx, gz, ge):
     x, rowop, colop, a, z, edge_e, den = ctx.saved_tensors
-    graph, att, H, f_in, f_out, sage = ctx.cfg
+    graph, att, H, f_in, f_out, sage, drop = ctx.cfg
     need_x, need_row, need_col, need_a = ctx.needs_input_grad[:4]
     dev = x.device
     n, e = graph.n, graph.nnz
@@ -42,7 +42,7 @@ def edge_backward(ctx, gz, ge):
     beta = torch.empty((H, e), dtype=torch.float32, device=dev)
     _lib.call("disgat_bwd_alpha", wi.items.data_ptr(), wi.n_items, graph.col.data_ptr(), e, H, f_in, x.data_ptr(),
               x.stride(0), gz.data_ptr(), z.data_ptr(), edge_e.data_ptr(), den.data_ptr(), ops._ptr(ge), ge_tot.data_ptr(),
-              beta.data_ptr(), int(bool(sage)), ops._stream())
+              beta.data_ptr(), int(bool(sage)), float(drop[0]), int(drop[1]), ops._stream())
     g_x = g_row = g_col = g_a = None
     t = twi = None
     if need_x or (att == 3 and need_col):

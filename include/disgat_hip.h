@@ -34,7 +34,11 @@
  *   x       [N][ldx]    layer input, F_in valid columns (F_in % 4 == 0 after padding)
  *   Z       [N][H][F_in] attention-weighted neighbour sums  sum_k alpha_k * x[col_k]
  *   edge_e  [H][E]      raw pre-sigmoid scores in CSR (= coalesced, row-major) edge order
- *   den     [N][H]      softmax denominators sum_k exp(sigmoid(e_k)) (saved for backward)
+ *   den     [N][2][H]   [.][0][h] softmax denominator sum_k exp(sigmoid(e_k)); [.][1][h] the same sum
+ *                       over the edges attention-dropout kept, scaled 1/(1-p) (== [0] when p = 0)
+ *   part_z / part_den   [n_slots][H][F_in] / [n_slots][2][H] partial records of split rows
+ *   drop_p, drop_seed   attention dropout (layers.py:394): edge k, head h is kept iff the top 32 bits
+ *                       of splitmix64(seed + (k*H+h)*0x9E3779B97F4A7C15) >= p*2^32; p = 0 disables it
  *   H must be a power of two (the host pads missing heads with zero weights).
  *
  * att (the reference's --att / att_type):
@@ -67,7 +71,7 @@ int disgat_edge_fwd(int att, const int32_t* items, int n_items, const int32_t* c
                     const float* a,
                     float* Z, float* edge_e, float* den,
                     float* part_z, float* part_den,
-                    int sage_div,
+                    int sage_div, float drop_p, uint64_t drop_seed,
                     disgat_stream_t stream);
 
 /* Sums the partial records of split rows (in chunk order: deterministic) and normalises. */
@@ -98,7 +102,7 @@ int disgat_pair_loss(const float* aux, int64_t M, int h_lo, int h_hi, const floa
 int disgat_bwd_alpha(const int32_t* items, int n_items, const int32_t* col, int64_t E, int H, int F_in,
                      const float* x, int ldx, const float* gZ, const float* Z, const float* edge_e,
                      const float* den, const float* ge_in, float* ge_out, float* beta, int sage_div,
-                     disgat_stream_t stream);
+                     float drop_p, uint64_t drop_seed, disgat_stream_t stream);
 
 /* Segment gradient of the att-3 score e = sum_f a_f lrelu(keyop[key] + otherop[other]).
  * items = {key, m_begin, m_end, slot} over a list sorted by key; other[m] = gathered node of list
