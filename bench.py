@@ -180,10 +180,17 @@ def main():
     if world != o.gpus and world > 1:
         raise SystemExit(f"--gpus {o.gpus} but WORLD_SIZE={world}")
     import torch.distributed as dist
+    # rehearsal on a one-GPU box: DISGAT_BENCH_REHEARSAL=1 puts every rank on cuda:0 over gloo
+    rehearsal = os.environ.get("DISGAT_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 

@@ -1,0 +1,111 @@
+"""world_size-2 `gloo` tests (CPU) of the row-range sharding: partition covers every edge once,
+the per-layer all-gather (equal and ragged row counts, with autograd), and the global loss
+reduction.  The edge math itself is stood in for by the oracle (tests only)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import inputs_common as ic
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from edgedisentangle_ssl_amd import parallel
+        from edgedisentangle_ssl_amd.graph import CSRGraph
+        from oracle import disgat_oracle as orc
+        from test_oracle_golden import shapes_layer
+
+        idx, vals, n = ic.tiny_graph()
+        g = CSRGraph.from_index(idx, n)
+        dg = parallel.DistGraph.shard(g, rank, world)
+        assert sum(dg.counts) == n and dg.n == dg.counts[rank]
+        # every edge owned exactly once, in global CSR order
+        nnz = torch.tensor([dg.nnz])
+        dist.all_reduce(nnz)
+        assert int(nnz) == g.nnz
+        lo = dg.row_start
+        e0 = int(g.rowptr[lo])
+        assert torch.equal(dg.col, g.col[e0:e0 + dg.nnz])
+        assert torch.equal(dg.row + lo, g.row[e0:e0 + dg.nnz])
+        # balanced by nnz, not by rows
+        assert abs(dg.nnz - g.nnz / world) <= g.nnz * 0.25 + 45
+
+        # all-gather of the layer input: ragged counts + autograd (sum of grads lands on the owner)
+        x = ic.features(21, n, 16)
+        xl = x[lo:lo + dg.n].clone().requires_grad_(True)
+        xa = parallel.all_gather_rows(xl, dg)
+        assert torch.equal(xa.detach(), x)
+        w = torch.arange(n, dtype=torch.float32).unsqueeze(1) * (rank + 1)
+        (xa * w).sum().backward()
+        want = (torch.arange(n, dtype=torch.float32).unsqueeze(1) * 3.0).expand(n, 16)[lo:lo + dg.n]
+        assert torch.allclose(xl.grad, want)
+        # equal counts -> all_gather_into_tensor path
+        eq = parallel.DistGraph(4, dg.rowptr[:5], dg.col, dg.row, 4 * world, 4 * rank, [4] * world)
+        xe = parallel.all_gather_rows(torch.full((4, 3), float(rank)), eq)
+        assert torch.equal(xe, torch.arange(world, dtype=torch.float32).repeat_interleave(4).unsqueeze(1).expand(-1, 3))
+
+        # one sharded layer (oracle as the math) == unsharded layer on the owned rows
+        p = ic.make_params(shapes_layer("SAGE", 3, 16, 16), 9)
+        ei_local = torch.stack([dg.row + lo, dg.col.long()])
+        h_loc, e_loc, _ = orc.disga_layer(xa.detach(), ei_local, p, 3, "SAGE")
+        h_all, e_all, _ = orc.disga_layer(x, g.indices(), p, 3, "SAGE")
+        assert torch.allclose(h_loc[lo:lo + dg.n], h_all[lo:lo + dg.n], atol=1e-6)
+        assert torch.allclose(e_loc, e_all[e0:e0 + dg.nnz], atol=1e-6)
+
+        # global pair loss from per-rank partial sums (what pretrainer.pair_mse_loss reduces)
+        pairs, lab = ic.sample_pairs(31, n, np.sort((g.row * n + g.col.long()).numpy()), "sup")
+        mine = (pairs[0] >= lo) & (pairs[0] < lo + dg.n)
+        pred = torch.sigmoid(torch.sin(pairs[0].float() * 0.37 + pairs[1].float()))
+        d2 = (pred - lab) ** 2
+        acc = torch.tensor([float(d2[mine & (lab != 0)].sum()), float(d2[mine & (lab == 0)].sum()),
+                            float((lab[mine] != 0).sum()), float(mine.sum())], dtype=torch.float64)
+        parallel.all_reduce_sum(acc, dg)
+        m = acc[3]
+        loss = (acc[0] + acc[2] / (m * m - acc[2]) * acc[1]) / m
+        assert abs(float(loss) - float(orc.adj_mse_loss(pred, lab))) < 1e-7
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc()))
+
+
+def test_row_sharding_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in res:
+        assert msg == "ok", f"rank {rank}:\n{msg}"
+
+
+def test_balanced_ranges_skewed():
+    from edgedisentangle_ssl_amd.parallel import balanced_row_ranges
+    deg = torch.tensor([1000] + [1] * 999)
+    rp = torch.zeros(1001, dtype=torch.int64)
+    rp[1:] = torch.cumsum(deg, 0)
+    b = balanced_row_ranges(rp, 4)
+    assert b[0] == 0 and b[-1] == 1000 and torch.all(b[1:] >= b[:-1])
+    per = [int(rp[b[i + 1]] - rp[b[i]]) for i in range(4)]
+    assert max(per) <= 1000 + 2 and sum(per) == int(rp[-1])
