@@ -112,6 +112,34 @@ class DisGALayer(nn.Module):
         return out, edge_e[0]
 
 
+class _HeadProject(torch.autograd.Function):
+    """out[:, h*F:(h+1)*F] = zt[h] @ w[h] (+ init), one strided-batched GEMM whose output lands in
+    the concatenated-heads layout [N, H*F_out] (ldc = H*F_out, batch stride F_out)."""
+
+    @staticmethod
+    def forward(ctx, zt, w, init):
+        H, n, _ = zt.shape
+        f_out = w.shape[2]
+        out = torch.empty((n, H * f_out), dtype=zt.dtype, device=zt.device)
+        o3 = out.view(n, H, f_out).permute(1, 0, 2)
+        if init is None:
+            torch.bmm(zt, w, out=o3)
+        else:
+            torch.baddbmm(init.reshape(n, H, f_out).permute(1, 0, 2), zt, w, out=o3)
+        ctx.save_for_backward(zt, w)
+        ctx.has_init = init is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        zt, w = ctx.saved_tensors
+        H, n, _ = zt.shape
+        g3 = g.view(n, H, -1).permute(1, 0, 2)
+        gz = torch.bmm(g3, w.transpose(1, 2)) if ctx.needs_input_grad[0] else None
+        gw = torch.bmm(zt.transpose(1, 2), g3) if ctx.needs_input_grad[1] else None
+        return gz, gw, (g if ctx.has_init and ctx.needs_input_grad[2] else None)
+
+
 class HeadList(list):
     """List of the H per-head outputs [N,F_out] (what the reference's fusers receive,
     models.py:230-233).  All heads are column slices of ONE buffer `fused` [N, H*F_out], which a
@@ -191,22 +219,24 @@ def disga_heads(layers, x, adj, aux_indices=None, head_ranges=None):
     cfg = (graph, att, Hp, f_in_p, f_out_p, gnn == "SAGE", drop)
     z, edge_e, _den = ops.EdgePass.apply(xg, rowop, colop, a_vec, cfg)
 
-    # ---- per-head output projection on the aggregated neighbourhood (dense, MFMA)
+    # ---- per-head output projection on the aggregated neighbourhood (dense, MFMA), written
+    # straight into the fused [N, H*F_out] layout the fuser consumes (no torch.cat of heads)
     zt = z[:, :H, :f_in].permute(1, 0, 2)                               # [H,N,F_in] strided view
     if gnn == "AT":                                                      # layers.py:397-399
         w = torch.stack([l.W_em for l in layers])                        # [H,F_in,F_out]
-        h3 = torch.bmm(zt, w)
+        fused = _HeadProject.apply(zt, w, None)
     elif gnn == "SAGE":                                                  # layers.py:96-110
         wx = torch.cat([l.ag_layer.proj.weight[:, :f_in].t() for l in layers], dim=1)   # [F_in, H*F_out]
         wn = torch.stack([l.ag_layer.proj.weight[:, f_in:].t() for l in layers])        # [H,F_in,F_out]
-        hx = (x @ wx).view(-1, H, f_out).permute(1, 0, 2)
-        h3 = torch.baddbmm(hx, zt, wn)
+        fused = _HeadProject.apply(zt, wn, x @ wx)
     else:                                                                # layers.py:38-54
         w = torch.stack([l.ag_layer.weight for l in layers])
-        b = torch.stack([l.ag_layer.bias for l in layers]).unsqueeze(1)  # [H,1,F_out]
-        h3 = torch.baddbmm(b, zt, w)
-    heads = HeadList(F.elu(h3).unbind(0))                                # layers.py:508-509
-    heads.pre_elu = h3.unbind(0)
+        b = torch.cat([l.ag_layer.bias for l in layers])                 # [H*F_out]
+        fused = _HeadProject.apply(zt, w, b.expand(z.shape[0], -1))
+    act = F.elu(fused)                                                   # layers.py:508-509
+    heads = HeadList(act[:, h * f_out:(h + 1) * f_out] for h in range(H))
+    heads.fused = act
+    heads.pre_elu = [fused[:, h * f_out:(h + 1) * f_out] for h in range(H)]
 
     e_list = [edge_e[h].unsqueeze(1) for h in range(H)]
 

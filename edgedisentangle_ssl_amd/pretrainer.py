@@ -203,17 +203,37 @@ class DifHeadTrainer(Trainer):
         return self.models[0].get_edge_em(feature, adj, [self.fuse1, self.fuse2])
 
     def loss(self, data):
-        edge_embeds = self.inference(data)
+        """sum over layers and heads of NLL(log_softmax(MLP(cat(layer_in, head_out_i))), i)
+        (pretrainer.py:819-832).  cat(in, out_i) @ W1^T splits into in @ W1[:, :F_in]^T, shared by
+        all heads of a layer, plus out_i @ W1[:, F_in:]^T, so the [N, F_in+nhid] concatenations the
+        reference builds per head (models.py:347, 365) are never materialised here; get_edge_em()
+        still returns them for callers that want them."""
+        feature, adj = data
+        r = self.models[0]._run(feature, adj, [self.fuse1, self.fuse2])
+        g = graph_of(adj)
+        sharded = isinstance(g, parallel.DistGraph) and g.world > 1
         loss = None
-        for layer, edge_embed in enumerate(edge_embeds):
+        for layer, (inp, heads) in enumerate(((r["x"], r["heads"][0]), (r["feature_1"], r["heads"][1]))):
             classifier = self.classifier1 if layer == 0 else self.classifier2
-            for i, edge in enumerate(edge_embed):
-                pred_label = classifier(edge, cls=True)
-                g = graph_of(data[1])
-                if isinstance(g, parallel.DistGraph) and g.world > 1:   # global mean over all ranks' nodes
+            mods = list(classifier.model)
+            if len(mods) < 3 or not isinstance(mods[0], torch.nn.Linear):     # cls_layer == 1: no shared part
+                outs = [classifier(torch.cat((inp, h), dim=-1), cls=True) for h in heads]
+            else:
+                lin = mods[0]
+                f_in = inp.shape[1]
+                shared = F.linear(inp, lin.weight[:, :f_in], lin.bias)
+                w_h = lin.weight[:, f_in:]
+                outs = []
+                for h in heads:
+                    t = shared + F.linear(h, w_h)
+                    for m in mods[1:]:
+                        t = m(t)
+                    outs.append(F.log_softmax(t, dim=1))
+            for i, pred_label in enumerate(outs):
+                if sharded:     # global mean over all ranks' nodes
                     term = -parallel.all_reduce_sum(pred_label[:, i].sum(), g) / g.n_global
                 else:
-                    term = -pred_label[:, i].mean()             # NLLLoss against the constant label i
+                    term = -pred_label[:, i].mean()                 # NLLLoss against the constant label i
                 loss = term if loss is None else loss + term
         return loss
 
