@@ -1,0 +1,98 @@
+"""`python -m edgedisentangle_ssl_amd.main ...`: the reference's main.py flow for --model=DISGAT
+(main.py:24-365): same flags, same alternation of downstream and SSL train_steps per epoch.
+
+Extra flags (not in the reference): --data_root (directory holding <dataset>/ in the reference's
+format) or --fixture (a tests/golden/data_<name>.npz file), --quiet.
+"""
+import random
+import sys
+import time
+
+import numpy as np
+import torch
+
+from . import data_load, models, pretrainer, trainer
+from .features import surrogate_features
+from .utils import get_parser
+
+SSL = {"DisEdge": pretrainer.GeneratedEdgeTrainer, "SupEdge": pretrainer.SupEdgeTrainer, "DifHead": pretrainer.DifHeadTrainer}
+
+
+def run(argv=None, log=print):
+    parser = get_parser()
+    parser.add_argument("--data_root", type=str, default="data")
+    parser.add_argument("--fixture", type=str, default=None)
+    parser.add_argument("--quiet", action="store_true", default=False)
+    args = parser.parse_args(argv)
+    if args.model != "DISGAT":
+        raise SystemExit("only --model=DISGAT is implemented by this package (SURVEY 2: other encoders out of scope)")
+    if not torch.cuda.is_available() or args.no_cuda:
+        raise SystemExit("the DISGAT HIP path needs an MI355X; there is no CPU fallback")
+    args.cuda = True
+    args.hetero = True                                  # main.py:29-30 (pretrain given) - adjs is a list
+    args.sparse = True
+    random.seed(args.seed)                              # main.py:44-48
+    np.random.seed(args.seed)
+    torch.manual_seed(args.seed)
+    torch.cuda.manual_seed(args.seed)
+    if args.pre_weight is None:
+        args.pretrain = []
+    unsupported = [p for p in (args.pretrain or []) if p not in SSL]
+    if unsupported:
+        raise SystemExit("SSL tasks {} are outside the DISGAT hot path (SURVEY 2 row 19)".format(unsupported))
+
+    if args.fixture:
+        adj, features, labels = data_load.load_fixture(args.fixture)
+        if features is None:
+            features = surrogate_features(adj.shape[0], 64, seed=51)
+        adjs = [adj]
+    else:
+        args.edge_num = 1
+        adjs, features, labels = data_load.load_data(args, path="{}/{}/".format(args.data_root, args.dataset),
+                                                     dataset=args.dataset, edge_type=args.edge_num)
+    args.size = features.shape[1]
+    args.nclass = labels.max().item() + 1
+    dev = torch.device("cuda")
+    features, labels = features.to(dev), labels.to(dev)
+    adjs = [a.to(dev) for a in adjs]
+
+    encoder = models.DISGAT(args, nfeat=args.size, nhid=args.nhid, nclass=args.nhid, nheads=args.nhead,
+                            dropout=args.dropout).to(dev)                  # main.py:142-147
+    ssl_trainers, ssl_labels = [], []
+    for i, name in enumerate(args.pretrain or []):                        # main.py:242-251
+        assert args.pre_edge[i] > 0, "edge index begins from 1"
+        tr = SSL[name](args, encoder, args.pre_weight[i])
+        a = adjs[args.used_edge - 1]
+        ssl_labels.append(tr.get_label_all(features, a, labels) if name == "DisEdge" else tr.get_label_all(features, a))
+        ssl_trainers.append(tr)
+    down = []
+    for i, name in enumerate(args.downstream or []):                      # main.py:255-258
+        if name != "CLS":
+            raise SystemExit("downstream 'Edge' is declared unfinished by the reference (README.md:23)")
+        down.append(trainer.ClsTrainer(args, encoder, labels, args.down_weight[0]))
+
+    history = []
+    t0 = time.time()
+    for epoch in range(args.epochs):                                      # main.py:270-360
+        adj = adjs[args.used_edge - 1]
+        log_ep = {"epoch": epoch}
+        if epoch % 40 == 0:
+            for i, tr in enumerate(down):
+                log_ep.update({"test_" + k: v for k, v in tr.test([features, adj], labels, epoch).items()})
+        if args.finetune:
+            for _ in range(args.steps):
+                for tr in down:
+                    log_ep.update(tr.train_step([features, adj], labels, epoch))
+        for i, tr in enumerate(ssl_trainers):
+            a = adjs[args.pre_edge[i] - 1]
+            log_ep.update(tr.train_step([features, a], ssl_labels[i]))
+        history.append(log_ep)
+        if not args.quiet:
+            log(" ".join("{}={:.5g}".format(k, v) if isinstance(v, float) else "{}={}".format(k, v) for k, v in log_ep.items()))
+    if not args.quiet:
+        log("Optimization Finished!  Total time elapsed: {:.4f}s".format(time.time() - t0))
+    return history
+
+
+if __name__ == "__main__":
+    run(sys.argv[1:])
