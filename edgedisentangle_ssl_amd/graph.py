@@ -66,6 +66,7 @@ class CSRGraph:
         self.rowptr = rowptr
         self.col = col
         self.row = row                      # int64 [E] (kept for host-side consumers / tests)
+        self.n_cols = self.n                # number of nodes a column id can name (> n on a row shard)
         self.nnz = int(col.shape[0])
         self.device = col.device
         self._items = {}
@@ -114,10 +115,10 @@ class CSRGraph:
         if self._transpose is None:
             colL = self.col.to(torch.int64)
             order = torch.sort(colL, stable=True).indices
-            counts = torch.bincount(colL, minlength=self.n)
-            tp = torch.zeros(self.n + 1, dtype=torch.int64, device=self.device)
+            counts = torch.bincount(colL, minlength=self.n_cols)
+            tp = torch.zeros(self.n_cols + 1, dtype=torch.int64, device=self.device)
             tp[1:] = torch.cumsum(counts, 0)
-            t = CSRGraph(self.n, tp.to(torch.int32).contiguous(), self.row[order].to(torch.int32).contiguous(),
+            t = CSRGraph(self.n_cols, tp.to(torch.int32).contiguous(), self.row[order].to(torch.int32).contiguous(),
                          colL[order].contiguous())
             t.eid = order.to(torch.int32).contiguous()
             self._transpose = t

@@ -66,7 +66,7 @@ def edge_backward(ctx, gz, ge):
     if need_x:
         g_x = _buf(tuple(x.shape), dev, twi.n_split > 0 or x.stride(0) != f_in)
         # grad of the aggregation: gx[c] = sum_{k in col c} sum_h beta_kh gZ[row_k,h,:]
-        _seg_hx(1, twi, t.col, t.eid, beta, 0, H, H, f_in, gz.view(n, H * f_in), g_x, False)
+        _seg_hx(1, twi, t.col, t.eid, beta, 0, H, H, f_in, gz.view(n, H * f_in), g_x, False)   # n rows of gZ, g_x over all columns
         if att == 2:                                    # e = <P[r,h,:], x[c,:]>  ->  gx[c] += sum_h ge_kh P[r_k,h,:]
             _seg_hx(1, twi, t.col, t.eid, ge_tot, 0, H, H, f_in, rowop, g_x, True)
     return g_x, g_row, g_col, g_a, None

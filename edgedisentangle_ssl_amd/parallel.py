@@ -9,7 +9,8 @@ halo is ~all of N, so the exchange is one all-gather of the layer input x per la
 which would move G x more); the column-side score operand (att 3: Q = x W_bot, H*F_out wide) is
 then recomputed locally from the gathered x instead of being exchanged (8x fewer bytes on the
 per-link-bound xGMI mesh; the redundant GEMM is cheaper than 7 links x ~50 GB/s).  Loss terms
-reduce with one all-reduce of three doubles.
+reduce with one all-reduce of a few doubles; in training the replicated parameters' gradients are
+summed with one bucketed all-reduce per step (classic data parallelism).
 """
 import torch
 import torch.distributed as dist
@@ -35,6 +36,7 @@ class DistGraph(CSRGraph):
     def __init__(self, n_local, rowptr, col, row, n_global, row_start, counts, group=None):
         super().__init__(n_local, rowptr, col, row)
         self.n_global = int(n_global)
+        self.n_cols = self.n_global
         self.row_start = int(row_start)
         self.counts = [int(c) for c in counts]          # rows owned by every rank
         self.group = group
@@ -60,9 +62,6 @@ class DistGraph(CSRGraph):
         counts = (b[1:] - b[:-1]).tolist()
         return DistGraph(hi - lo, (rp[lo:hi + 1] - e0).to(torch.int32).contiguous(), graph.col[e0:e1].contiguous(),
                          (graph.row[e0:e1] - lo).contiguous(), graph.n, lo, counts, group)
-
-    def transpose(self):
-        raise NotImplementedError("backward over a sharded graph is not built yet (SURVEY 8f-1)")
 
 
 class _AllGatherRows(torch.autograd.Function):
@@ -97,6 +96,22 @@ def all_gather_rows(x_local, graph):
     if not isinstance(graph, DistGraph) or graph.world == 1:
         return x_local
     return _AllGatherRows.apply(x_local, graph.counts, graph.group)
+
+
+def all_reduce_grads(modules, graph):
+    """Data-parallel gradient reduction: every rank holds the replicated parameters and the gradient
+    contribution of its own rows / pairs; the global gradient is their sum."""
+    if not (isinstance(graph, DistGraph) and graph.world > 1):
+        return
+    grads = [p.grad for m in modules for p in m.parameters() if p.grad is not None]
+    if not grads:
+        return
+    flat = torch.cat([g.reshape(-1) for g in grads])          # one bucket: a few MB of parameters
+    dist.all_reduce(flat, group=graph.group)
+    off = 0
+    for g in grads:
+        g.copy_(flat[off: off + g.numel()].view_as(g))
+        off += g.numel()
 
 
 def all_reduce_sum(t, graph):

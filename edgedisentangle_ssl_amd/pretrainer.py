@@ -39,10 +39,18 @@ def pair_mse_loss(aux, h_lo, h_hi, labels, graph=None):
         m = acc[3]
         neg_w = acc[2] / (m * m - acc[2])
         return ((acc[0] + neg_w * acc[1]) / m).to(torch.float32)
-    if sharded:
-        raise NotImplementedError("differentiable pair loss over a sharded graph is not built yet")
-    pred = torch.sigmoid(torch.sum(torch.stack(heads), dim=0))
-    return adj_mse_loss(pred.squeeze(-1), labels)
+    pred = torch.sigmoid(torch.sum(torch.stack(heads), dim=0)).squeeze(-1)
+    if not sharded:
+        return adj_mse_loss(pred, labels)
+    # sharded + autograd: class weights and the mean use GLOBAL counts; this rank contributes the
+    # weighted squared error of its own pairs (the value returned is the global loss, its gradient
+    # the local part - parameter gradients are summed over ranks afterwards)
+    cnt = torch.tensor([float((labels != 0).sum()), float(labels.shape[0])], dtype=torch.float64, device=labels.device)
+    parallel.all_reduce_sum(cnt, graph)
+    neg_w = (cnt[0] / (cnt[1] * cnt[1] - cnt[0])).to(pred.dtype)
+    w = torch.where(labels == 0, neg_w, torch.ones((), dtype=pred.dtype, device=pred.device))
+    local = (w * (pred - labels) ** 2).sum() / cnt[1].to(pred.dtype)
+    return local + (parallel.all_reduce_sum(local.detach().clone(), graph) - local.detach())
 
 
 class Trainer(object):
@@ -66,8 +74,9 @@ class Trainer(object):
             model.train()
             self.models_opt[i].zero_grad()
 
-    def _finish_step(self, loss):
+    def _finish_step(self, loss, graph=None):
         (loss * self.loss_weight).backward()
+        parallel.all_reduce_grads(self.models, graph)
         if self.loss_weight != 0:
             for opt in self.models_opt:
                 opt.step()
@@ -114,7 +123,7 @@ class SupEdgeTrainer(Trainer):
         self._begin_step()
         labels, indices = self.sample_train(gt_adj if gt_adj is not None else data[1])
         loss = self.loss(data, labels, indices)
-        self._finish_step(loss)
+        self._finish_step(loss, graph_of(data[1]))
         return {"loss_heads_sup": loss.item()}
 
 
@@ -174,7 +183,7 @@ class GeneratedEdgeTrainer(Trainer):
         self._begin_step()
         adj_labels, adj_masks = self.sample_train()
         loss = self.loss(data, adj_labels, adj_masks)
-        self._finish_step(loss)
+        self._finish_step(loss, graph_of(data[1]))
         return {"loss_head_disen": loss.item()}
 
 
@@ -230,8 +239,9 @@ class DifHeadTrainer(Trainer):
                         t = m(t)
                     outs.append(F.log_softmax(t, dim=1))
             for i, pred_label in enumerate(outs):
-                if sharded:     # global mean over all ranks' nodes
-                    term = -parallel.all_reduce_sum(pred_label[:, i].sum(), g) / g.n_global
+                if sharded:     # global mean over all ranks' nodes (value global, gradient = local part)
+                    loc = -pred_label[:, i].sum() / g.n_global
+                    term = loc + (parallel.all_reduce_sum(loc.detach().clone(), g) - loc.detach())
                 else:
                     term = -pred_label[:, i].mean()                 # NLLLoss against the constant label i
                 loss = term if loss is None else loss + term
@@ -240,5 +250,5 @@ class DifHeadTrainer(Trainer):
     def train_step(self, data, pre_dif=None):
         self._begin_step()
         loss = self.loss(data)
-        self._finish_step(loss)
+        self._finish_step(loss, graph_of(data[1]))
         return {"loss_head_diversity": loss.item()}

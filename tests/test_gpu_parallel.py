@@ -73,6 +73,32 @@ def _worker(rank, world, port, q, golden_dir):
                 assert err <= 1e-5 * max(1.0, ref_em[l].abs().max().item()), (gnn, att, l, err)
             for nm, got, want in (("sup", l_sup, ref_sup), ("dis", l_dis, ref_dis), ("dif", l_dif, ref_dif)):
                 assert abs(got.item() - want.item()) <= 2e-6 * max(1.0, abs(want.item())), (gnn, att, nm, got.item(), want.item())
+
+            # training: sharded backward + gradient all-reduce == unsharded gradients
+            def grads_of(fn, mods, graph):
+                for m in mods:
+                    for p in m.parameters():
+                        p.grad = None
+                loss = fn()
+                loss.backward()
+                parallel.all_reduce_grads(mods, graph)
+                return loss.item(), [None if p.grad is None else p.grad.clone() for m in mods for p in m.parameters()]
+
+            for nm, tr, full, part in (
+                    ("sup", sup_t, lambda: sup_t.loss((x, g), sup[1].to(dev), [sup[0].to(dev)]),
+                     lambda: sup_t.loss((xl, dg), sl, [si])),
+                    ("dis", dis_t, lambda: dis_t.loss((x, g), [ho[1].to(dev), he[1].to(dev)], [ho[0].to(dev), he[0].to(dev)]),
+                     lambda: dis_t.loss((xl, dg), [hl, tl], [hi_, ti])),
+                    ("dif", dif_t, lambda: dif_t.loss((x, g)), lambda: dif_t.loss((xl, dg)))):
+                lv_ref, g_ref = grads_of(full, tr.models, g)
+                lv, g_sh = grads_of(part, tr.models, dg)
+                assert abs(lv - lv_ref) <= 2e-6 * max(1.0, abs(lv_ref)), (gnn, att, nm, lv, lv_ref)
+                for a_, b_ in zip(g_sh, g_ref):
+                    if b_ is None:
+                        assert a_ is None or float(a_.abs().max()) == 0.0
+                        continue
+                    err = (a_ - b_).abs().max().item()
+                    assert err <= 2e-4 * max(1e-3, b_.abs().max().item()), (gnn, att, nm, err, b_.abs().max().item())
         dist.barrier()
         dist.destroy_process_group()
         q.put((rank, "ok"))
