@@ -34,7 +34,7 @@ def pair_mse_loss(aux, h_lo, h_hi, labels, graph=None):
              and heads[0].data_ptr() == base[h_lo].data_ptr())
     if fused and not (torch.is_grad_enabled() and any(h.requires_grad for h in heads)):
         acc = ops.pair_loss_sums(base, h_lo, h_hi, labels)
-        acc = torch.cat([acc, torch.tensor([float(labels.shape[0])], dtype=torch.float64, device=acc.device)])
+        acc = torch.cat([acc, acc.new_full((1,), float(labels.shape[0]))])     # fill kernel: stays graph-capturable
         parallel.all_reduce_sum(acc, graph)
         m = acc[3]
         neg_w = acc[2] / (m * m - acc[2])
