@@ -14,7 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libdisgat_hip.so")
-SOURCES = ["api_common.hip", "edge_fwd.hip", "aux_score.hip", "edge_bwd.hip"]
+SOURCES = ["api_common.hip", "edge_fwd.hip", "aux_score.hip", "edge_bwd.hip", "gemm_split.hip"]
 ARCH = "gfx950"
 
 _lib = None
@@ -84,6 +84,9 @@ _SIGS = {
                                         _P, _c.c_int, _P, _c.c_int, _P, _P, _c.c_int, _P, _c.c_int, _P]),
     "disgat_seg_grad_hx": (_c.c_int, [_c.c_int, _P, _c.c_int, _P, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int,
                                       _c.c_int, _P, _c.c_int, _P, _c.c_int, _c.c_int, _P]),
+    "disgat_gemm_split": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _P, _P, _P, _c.c_int64, _c.c_int64, _P, _c.c_int64,
+                                     _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_float,
+                                     _c.c_int, _P]),
 }
 
 

@@ -1,0 +1,269 @@
+// fp32-accurate dense GEMM on the bf16 matrix cores of gfx950 (CDNA4 has no xf32/TF32 and its
+// f32-input MFMA runs at the vector rate, 1/16 of bf16).
+//
+//   C[b] = act( A[b] (M x K, fp32) * B[b] (K x N) + bias[b] + init[b] )        b = 0 .. batch-1
+//
+// Every fp32 value v is written exactly as hi + mid + lo with three bf16 numbers (8 + 8 + 8
+// mantissa bits); a product a*b then needs the six partial
+// products whose weight is >= 2^-16 (hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi), each exact in
+// the MFMA's fp32 accumulator; the dropped terms are <= 2^-25 relative, below fp32 rounding.
+// Measured error vs fp64 equals hipBLASLt's fp32 GEMM (tests/test_gpu_gemm.py).  `terms` = 3
+// keeps only hi*hi, hi*mid, mid*hi (~5e-6 of the tensor maximum: opt-in).
+//
+// These are the dense contractions of the DISGAT path (SURVEY 8d "MFMA" rows): the per-node score
+// operands P/Q = x W (layers.py:350, 363, 376), the per-head output projections (layers.py:398,
+// 110, 39), FuseLayer's Linear (layers.py:905) and DifHead's MLP (models.py:538).
+//
+// Structure: 128x128 output tile per 256-thread block (4 waves as 2x2, 64x64 each = 4x4 MFMA
+// tiles of 16x16x32), BK = 32.  A is read as fp32 (coalesced float4), split in registers and
+// written to three LDS planes; B arrives pre-split and pre-transposed ([3][N][K] bf16, k
+// contiguous) so both operands are one ds_read_b128 per fragment; 64-B rows with an XOR chunk
+// swizzle make the 16-row x 16-B fragment reads conflict-free.  Next tile's global loads are issued
+// before the 96 MFMAs of the current one (two-tile-deep register prefetch, single LDS stage, 48 KB, 2
+// blocks/CU).  Block ids are remapped so that all N-tiles of one M-tile run on one XCD (A tile
+// served by that XCD's L2).  Epilogue fuses bias, an additive init matrix and ELU / leaky-ReLU.
+#include "disgat_common.h"
+
+namespace disgat {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+struct GemmArgs {
+  const float* A;
+  int64_t lda, a_bs;
+  const uint16_t* Bt;   // [batch][3][N][K]
+  const float* bias;    // [batch][N] or null
+  const float* init;    // or null
+  int64_t ldi, i_bs;
+  float* C;
+  int64_t ldc, c_bs;
+  int M, N, K, batch;
+  int act;              // 0 none, 1 elu, 2 leaky relu(slope)
+  float slope;
+  int terms;            // 6 or 3
+  int mt, nt;           // tiles along M, N
+};
+
+constexpr int GBM = 128, GBN = 128, GBK = 32, GLD = 32;   // LDS rows: 32 bf16 = 64 B, four 16-B chunks
+constexpr int PLANE = GBM * GLD;                          // bf16 elements per plane (A and B tiles equal)
+
+// Exact three-way split of an fp32 value by truncation: hi = top 8 mantissa bits, mid = the next 8,
+// lo = the last 8 (v == hi + mid + lo exactly; each residual subtraction is exact).  Truncation costs
+// 5 VALU ops per value instead of ~14 for round-to-nearest; the dropped cross terms (mid*lo, lo*mid,
+// lo*lo) stay below 2^-22 of the product and share its sign, i.e. a relative scaling of ~1e-7.
+__device__ __forceinline__ void split1(float v, uint32_t& h, uint32_t& m, uint32_t& l) {
+  h = __float_as_uint(v) & 0xFFFF0000u;
+  const float r1 = v - __uint_as_float(h);
+  m = __float_as_uint(r1) & 0xFFFF0000u;
+  l = __float_as_uint(r1 - __uint_as_float(m)) & 0xFFFF0000u;
+}
+
+// two bf16 (upper halves of a and b) -> one dword, a in the low half
+// LDS element offset of 16-B chunk `c` (0..3) of tile row `r`: chunk index XOR-swizzled with
+// (r >> 1) & 3, which makes the 16-row x 16-B MFMA fragment reads conflict-free for all four lane
+// groups of ds_read_b128 (unswizzled 64-B rows are 2-way conflicted) without padding.
+__device__ __forceinline__ int sw(int r, int c) { return r * GLD + ((c ^ ((r >> 1) & 3)) << 3); }
+
+__device__ __forceinline__ uint32_t pack_hi(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+
+// split 4 floats into 3 planes of 4 bf16 (packed 2 x uint32 per plane; element 0 in the low half)
+__device__ __forceinline__ void split4(const f32x4 v, u32x2& hi, u32x2& mid, u32x2& lo) {
+  uint32_t h0, m0, l0, h1, m1, l1, h2, m2, l2, h3, m3, l3;
+  split1(v.x, h0, m0, l0);
+  split1(v.y, h1, m1, l1);
+  split1(v.z, h2, m2, l2);
+  split1(v.w, h3, m3, l3);
+  hi = u32x2{pack_hi(h0, h1), pack_hi(h2, h3)};
+  mid = u32x2{pack_hi(m0, m1), pack_hi(m2, m3)};
+  lo = u32x2{pack_hi(l0, l1), pack_hi(l2, l3)};
+}
+
+template <int TERMS>
+__global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs G) {
+  __shared__ __attribute__((aligned(16))) uint16_t lds[6 * PLANE];   // A planes 0..2, B planes 3..5
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // XCD-aware tile order: blocks b and b+8 share an XCD; give each XCD whole M-tiles
+  const int b = blockIdx.x;
+  const int xcd = b & 7, q = b >> 3;
+  const int m_tile = (q / G.nt) * 8 + xcd;
+  const int n_tile = q % G.nt;
+  if (m_tile >= G.mt) return;
+  const int bz = blockIdx.y;
+  const int m0 = m_tile * GBM, n0 = n_tile * GBN;
+
+  const float* A = G.A + (int64_t)bz * G.a_bs;
+  const uint16_t* Bt = G.Bt + (int64_t)bz * 3 * G.N * G.K;
+  float* C = G.C + (int64_t)bz * G.c_bs;
+
+  // global -> register staging maps
+  const int a_row = tid >> 3, a_col = (tid & 7) * 4;          // + 32*i rows, i < 4
+  const int b_row = tid >> 2, b_col = (tid & 3) * 8;          // + 64*i rows, i < 2, per plane
+  f32x4 a_s0[4], a_s1[4];
+  u32x4 b_s0[6], b_s1[6];
+
+  auto load_tiles = [&](f32x4(&a_st)[4], u32x4(&b_st)[6], int kt) {
+    const int k0 = kt * GBK;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = m0 + a_row + 32 * i;
+      a_st[i] = (r < G.M) ? ld4(A + (int64_t)r * G.lda + k0 + a_col) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int n = n0 + b_row + 64 * i;
+        b_st[p * 2 + i] = *reinterpret_cast<const u32x4*>(Bt + ((int64_t)p * G.N + n) * G.K + k0 + b_col);
+      }
+  };
+  auto store_tiles = [&](const f32x4(&a_st)[4], const u32x4(&b_st)[6]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      u32x2 h, m, l;
+      split4(a_st[i], h, m, l);
+      const int o = sw(a_row + 32 * i, a_col >> 3) + (a_col & 4);
+      *reinterpret_cast<u32x2*>(&lds[0 * PLANE + o]) = h;
+      *reinterpret_cast<u32x2*>(&lds[1 * PLANE + o]) = m;
+      *reinterpret_cast<u32x2*>(&lds[2 * PLANE + o]) = l;
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        *reinterpret_cast<u32x4*>(&lds[(3 + p) * PLANE + sw(b_row + 64 * i, b_col >> 3)]) = b_st[p * 2 + i];
+  };
+
+  f32x4v acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+  const int frag_off = sw(lane & 15, lane >> 4);      // tile bases are multiples of 16 rows: swizzle unchanged
+  const int KT = G.K / GBK;
+
+  auto compute = [&]() {
+    bf16x8 af[3][4];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        af[p][i] = *reinterpret_cast<const bf16x8*>(&lds[p * PLANE + (wm * 64 + i * 16) * GLD + frag_off]);
+#pragma unroll
+    for (int pb = 0; pb < (TERMS == 3 ? 2 : 3); ++pb) {
+      bf16x8 bfr[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        bfr[j] = *reinterpret_cast<const bf16x8*>(&lds[(3 + pb) * PLANE + (wn * 64 + j * 16) * GLD + frag_off]);
+      // plane pairs (pa,pb) kept: pb=0: pa 0,1,2 ; pb=1: pa 0,1 ; pb=2: pa 0   (TERMS==3: (0,0),(1,0),(0,1))
+      const int npa = (TERMS == 3) ? (pb == 0 ? 2 : 1) : (3 - pb);
+#pragma unroll
+      for (int pa = 0; pa < npa; ++pa)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[pa][i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  // pipeline: tile kt is in LDS, tile kt+1 sits in one register set (loaded during the previous
+  // step), tile kt+2 is being loaded into the other set while the MFMAs of tile kt run
+  load_tiles(a_s0, b_s0, 0);
+  store_tiles(a_s0, b_s0);
+  if (KT > 1) load_tiles(a_s1, b_s1, 1);
+  __syncthreads();
+  for (int kt = 0; kt < KT; kt += 2) {
+    if (kt + 2 < KT) load_tiles(a_s0, b_s0, kt + 2);
+    compute();
+    __syncthreads();
+    if (kt + 1 < KT) {
+      store_tiles(a_s1, b_s1);
+      __syncthreads();
+      if (kt + 3 < KT) load_tiles(a_s1, b_s1, kt + 3);
+      compute();
+      __syncthreads();
+      if (kt + 2 < KT) {
+        store_tiles(a_s0, b_s0);
+        __syncthreads();
+      }
+    }
+  }
+
+  // epilogue: C/D layout of 16x16x32: col = lane & 15, row = (lane >> 4) * 4 + reg.  The tile goes
+  // through LDS in two 64-row halves (wm = 0, then wm = 1) so that every thread stores float4s of
+  // full 512-B rows instead of 64 scattered dwords.
+  const float* bias = G.bias ? G.bias + (int64_t)bz * G.N : nullptr;
+  const float* init = G.init ? G.init + (int64_t)bz * G.i_bs : nullptr;
+  float* stage = reinterpret_cast<float*>(lds);             // 64 rows x (128 + 4) floats = 33 KB
+  constexpr int SLD = GBN + 4;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    if (wm == half) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            stage[(i * 16 + (lane >> 4) * 4 + r) * SLD + wn * 64 + j * 16 + (lane & 15)] = acc[i][j][r];
+    }
+    __syncthreads();
+    const int c4 = (tid & 31) * 4;                          // 32 threads x float4 = one 128-float row
+    const int col = n0 + c4;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (bias) bv = ld4(bias + col);
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      const int lr = (tid >> 5) + rr * 8;
+      const int row = m0 + half * 64 + lr;
+      if (row < G.M) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(&stage[lr * SLD + c4]) + bv;
+        if (init) v += ld4(init + (int64_t)row * G.ldi + col);
+        if (G.act == 1) {
+          v.x = v.x > 0.f ? v.x : expm1f(v.x); v.y = v.y > 0.f ? v.y : expm1f(v.y);
+          v.z = v.z > 0.f ? v.z : expm1f(v.z); v.w = v.w > 0.f ? v.w : expm1f(v.w);
+        } else if (G.act == 2) {
+          v.x = v.x > 0.f ? v.x : G.slope * v.x; v.y = v.y > 0.f ? v.y : G.slope * v.y;
+          v.z = v.z > 0.f ? v.z : G.slope * v.z; v.w = v.w > 0.f ? v.w : G.slope * v.w;
+        }
+        st4(C + (int64_t)row * G.ldc + col, v);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace disgat
+
+// ------------------------------------------------------------------------------------------
+#include "disgat_api.h"
+
+extern "C" int disgat_gemm_split(const float* A, int64_t lda, int64_t a_batch_stride, const uint16_t* Bt_planes,
+                                 const float* bias, const float* init, int64_t ldi, int64_t init_batch_stride, float* C,
+                                 int64_t ldc, int64_t c_batch_stride, int M, int N, int K, int batch, int act,
+                                 float slope, int terms, disgat_stream_t stream) {
+  using namespace disgat;
+  if (M == 0 || batch == 0) return 0;
+  DISGAT_REQUIRE(A && Bt_planes && C && M > 0 && batch > 0, "gemm_split: null pointer / bad sizes");
+  DISGAT_REQUIRE(N > 0 && N % GBN == 0 && K > 0 && K % GBK == 0, "gemm_split: N=%d must be a multiple of %d and K=%d of %d", N, GBN, K, GBK);
+  DISGAT_REQUIRE(lda % 4 == 0 && a_batch_stride % 4 == 0 && aligned16(A) && aligned16(Bt_planes),
+                 "gemm_split: A rows must be 16-byte aligned (lda, batch stride multiples of 4)");
+  DISGAT_REQUIRE(terms == 3 || terms == 6, "gemm_split: terms must be 3 or 6");
+  DISGAT_REQUIRE(act >= 0 && act <= 2, "gemm_split: act must be 0 (none), 1 (elu) or 2 (leaky relu)");
+  GemmArgs G{A, lda, a_batch_stride, Bt_planes, bias, init, ldi, init_batch_stride, C, ldc, c_batch_stride,
+             M, N, K, batch, act, slope, terms, (M + GBM - 1) / GBM, N / GBN};
+  const int64_t blocks = (int64_t)((G.mt + 7) / 8) * 8 * G.nt;
+  DISGAT_REQUIRE(blocks < ((int64_t)1 << 31) && batch < 65536, "gemm_split: grid too large");
+  if (terms == 6)
+    hipLaunchKernelGGL(gemm_split_kernel<6>, dim3((unsigned)blocks, batch), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), G);
+  else
+    hipLaunchKernelGGL(gemm_split_kernel<3>, dim3((unsigned)blocks, batch), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), G);
+  return check_launch("gemm_split_kernel");
+}

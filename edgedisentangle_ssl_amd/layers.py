@@ -17,7 +17,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops, parallel
+from . import ops, ops_gemm, parallel
 from .graph import CSRGraph, graph_of
 
 
@@ -112,34 +112,6 @@ class DisGALayer(nn.Module):
         return out, edge_e[0]
 
 
-class _HeadProject(torch.autograd.Function):
-    """out[:, h*F:(h+1)*F] = zt[h] @ w[h] (+ init), one strided-batched GEMM whose output lands in
-    the concatenated-heads layout [N, H*F_out] (ldc = H*F_out, batch stride F_out)."""
-
-    @staticmethod
-    def forward(ctx, zt, w, init):
-        H, n, _ = zt.shape
-        f_out = w.shape[2]
-        out = torch.empty((n, H * f_out), dtype=zt.dtype, device=zt.device)
-        o3 = out.view(n, H, f_out).permute(1, 0, 2)
-        if init is None:
-            torch.bmm(zt, w, out=o3)
-        else:
-            torch.baddbmm(init.reshape(n, H, f_out).permute(1, 0, 2), zt, w, out=o3)
-        ctx.save_for_backward(zt, w)
-        ctx.has_init = init is not None
-        return out
-
-    @staticmethod
-    def backward(ctx, g):
-        zt, w = ctx.saved_tensors
-        H, n, _ = zt.shape
-        g3 = g.view(n, H, -1).permute(1, 0, 2)
-        gz = torch.bmm(g3, w.transpose(1, 2)) if ctx.needs_input_grad[0] else None
-        gw = torch.bmm(zt.transpose(1, 2), g3) if ctx.needs_input_grad[1] else None
-        return gz, gw, (g if ctx.has_init and ctx.needs_input_grad[2] else None)
-
-
 class HeadList(list):
     """List of the H per-head outputs [N,F_out] (what the reference's fusers receive,
     models.py:230-233).  All heads are column slices of ONE buffer `fused` [N, H*F_out], which a
@@ -163,12 +135,12 @@ def _pack_score_operands(layers, x, x_all, att, H, Hp, f_in, f_out):
         zero = [x.new_zeros(f_in)] * (Hp - H)
         w1 = torch.stack([l.W @ l.a[:f_out, 0] for l in layers] + zero, dim=1)     # [F_in, Hp]
         w2 = torch.stack([l.W @ l.a[f_out:, 0] for l in layers] + zero, dim=1)
-        return x @ w1, x_all @ w2, None, f_out
+        return x @ w1, x_all @ w2, None, f_out                                     # N = Hp: too narrow for the MFMA tile
     if att == 2:
         f_in_p = (f_in + 3) // 4 * 4
         ms = [F.pad(l.W @ l.W.t(), (0, f_in_p - f_in)) for l in layers]
         ms += [x.new_zeros(f_in, f_in_p)] * (Hp - H)
-        return x @ torch.cat(ms, dim=1), None, None, f_out                         # [N, Hp*F_in_p]
+        return ops_gemm.linear(x, torch.cat(ms, dim=1)), None, None, f_out          # [N, Hp*F_in_p]
     g4 = (64 // Hp) * 4
     qn = _pow2ceil((f_out + g4 - 1) // g4)
     if qn > 8:
@@ -178,7 +150,8 @@ def _pack_score_operands(layers, x, x_all, att, H, Hp, f_in, f_out):
     tops = [F.pad(l.W[:f_in], (0, fp - f_out)) for l in layers] + [x.new_zeros(f_in, fp)] * (Hp - H)
     bots = [F.pad(l.W[f_in:], (0, fp - f_out)) for l in layers] + [x.new_zeros(f_in, fp)] * (Hp - H)
     a_vec = torch.cat([F.pad(l.a[:, 0], (0, fp - f_out)) for l in layers] + [x.new_zeros(fp)] * (Hp - H))
-    return x @ torch.cat(tops, dim=1), x_all @ torch.cat(bots, dim=1), a_vec.contiguous(), fp
+    return (ops_gemm.linear(x, torch.cat(tops, dim=1)), ops_gemm.linear(x_all, torch.cat(bots, dim=1)),
+            a_vec.contiguous(), fp)
 
 
 def disga_heads(layers, x, adj, aux_indices=None, head_ranges=None):
@@ -222,21 +195,23 @@ def disga_heads(layers, x, adj, aux_indices=None, head_ranges=None):
     # ---- per-head output projection on the aggregated neighbourhood (dense, MFMA), written
     # straight into the fused [N, H*F_out] layout the fuser consumes (no torch.cat of heads)
     zt = z[:, :H, :f_in].permute(1, 0, 2)                               # [H,N,F_in] strided view
+    concat = all(l.concat for l in layers)
+    act_code = ops_gemm.ACT_ELU if concat else ops_gemm.ACT_NONE         # ELU fused in the GEMM epilogue
     if gnn == "AT":                                                      # layers.py:397-399
         w = torch.stack([l.W_em for l in layers])                        # [H,F_in,F_out]
-        fused = _HeadProject.apply(zt, w, None)
+        fused = ops_gemm.linear(zt, w, None, None, act_code)
     elif gnn == "SAGE":                                                  # layers.py:96-110
         wx = torch.cat([l.ag_layer.proj.weight[:, :f_in].t() for l in layers], dim=1)   # [F_in, H*F_out]
         wn = torch.stack([l.ag_layer.proj.weight[:, f_in:].t() for l in layers])        # [H,F_in,F_out]
-        fused = _HeadProject.apply(zt, wn, x @ wx)
+        fused = ops_gemm.linear(zt, wn, None, ops_gemm.linear(x, wx), act_code)
     else:                                                                # layers.py:38-54
         w = torch.stack([l.ag_layer.weight for l in layers])
         b = torch.cat([l.ag_layer.bias for l in layers])                 # [H*F_out]
-        fused = _HeadProject.apply(zt, w, b.expand(z.shape[0], -1))
-    act = F.elu(fused)                                                   # layers.py:508-509
+        fused = ops_gemm.linear(zt, w, b, None, act_code)
+    act = fused if concat else F.elu(fused)                              # layers.py:508-509
     heads = HeadList(act[:, h * f_out:(h + 1) * f_out] for h in range(H))
     heads.fused = act
-    heads.pre_elu = [fused[:, h * f_out:(h + 1) * f_out] for h in range(H)]
+    heads.pre_elu = None if concat else [fused[:, h * f_out:(h + 1) * f_out] for h in range(H)]
 
     e_list = [edge_e[h].unsqueeze(1) for h in range(H)]
 
@@ -281,6 +256,9 @@ class FuseLayer(nn.Module):
         if self.args.residue_type == 0:
             if use_res:
                 features = torch.cat([features, residue], dim=-1)
+            if features.is_cuda and features.dim() == 2:     # Linear (+ leaky_relu) in one MFMA GEMM with fused epilogue
+                act = ops_gemm.ACT_NONE if self.args.fuse_no_relu else ops_gemm.ACT_LEAKY
+                return ops_gemm.linear(features, self.fuse.weight.t(), self.fuse.bias, None, act, 0.01)
             feature = self.fuse(features)
         elif self.args.residue_type == 1:
             if use_res:

@@ -1,0 +1,118 @@
+"""Dense contractions of the DISGAT path on the split-bf16 MFMA GEMM (csrc/gemm_split.hip).
+
+`linear(a, w, ...)` computes act(a @ w + bias + init) for a 2-D `a`, or for a head-batched view
+`a` [H, M, K] with `w` [H, K, N] writing the concatenated-heads layout [M, H*N].  Shapes outside
+the kernel's tiling (N % 128, K % 32) and DISGAT_GEMM=blas go to hipBLASLt through torch.matmul -
+still the GPU, still fp32.  DISGAT_GEMM=split3 selects the 3-product variant (not fp32-accurate;
+benchmark switch only).
+"""
+import os
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib, ops
+
+ACT_NONE, ACT_ELU, ACT_LEAKY = 0, 1, 2
+
+
+def mode():
+    return os.environ.get("DISGAT_GEMM", "split6")
+
+
+def split_weight(w):
+    """[..., K, N] fp32 -> int16 view of bf16 planes [..., 3, N, K] (hi, mid, lo of w^T, k contiguous)."""
+    wt = w.detach().transpose(-1, -2).contiguous()
+    hi = wt.to(torch.bfloat16)
+    r1 = wt - hi.float()
+    mid = r1.to(torch.bfloat16)
+    lo = (r1 - mid.float()).to(torch.bfloat16)
+    return torch.stack([hi, mid, lo], dim=-3).contiguous().view(torch.int16)
+
+
+def _apply_act(t, act, slope):
+    if act == ACT_ELU:
+        return F.elu(t)
+    if act == ACT_LEAKY:
+        return F.leaky_relu(t, slope)
+    return t
+
+
+def _kernel_ok(a, k, n):
+    return (mode() != "blas" and a.is_cuda and a.dtype == torch.float32 and n % 128 == 0 and k % 32 == 0
+            and a.stride(-1) == 1 and a.stride(-2) % 4 == 0 and a.data_ptr() % 16 == 0
+            and (a.dim() == 2 or a.stride(0) % 4 == 0))
+
+
+def _forward(a, w, bias, init, act, slope):
+    batched = a.dim() == 3
+    if batched:
+        hb, m, k = a.shape
+        n = w.shape[2]
+    else:
+        hb, (m, k), n = 1, a.shape, w.shape[1]
+    if not _kernel_ok(a, k, n):
+        if batched:
+            out3 = torch.bmm(a, w)
+            if bias is not None:
+                out3 = out3 + bias.view(hb, 1, n)
+            out = out3.permute(1, 0, 2).reshape(m, hb * n)
+        else:
+            out = a @ w
+            if bias is not None:
+                out = out + bias
+        if init is not None:
+            out = out + init
+        return _apply_act(out, act, slope)
+    out = torch.empty((m, hb * n), dtype=torch.float32, device=a.device)
+    planes = split_weight(w)
+    if init is not None and (init.stride(-1) != 1 or init.shape != out.shape):
+        init = init.expand(m, hb * n).contiguous()
+    if bias is not None:
+        bias = bias.contiguous()
+    _lib.call("disgat_gemm_split", a.data_ptr(), a.stride(-2), a.stride(0) if batched else 0, planes.data_ptr(),
+              ops._ptr(bias), ops._ptr(init), 0 if init is None else init.stride(0), n if batched else 0,
+              out.data_ptr(), out.stride(0), n if batched else 0, m, n, k, hb, act, float(slope),
+              3 if mode() == "split3" else 6, ops._stream())
+    return out
+
+
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, w, bias, init, act, slope):
+        out = _forward(a, w, bias, init, act, slope)
+        ctx.save_for_backward(a, w, out if act != ACT_NONE else None)
+        ctx.meta = (act, slope, bias is not None, init is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, w, out = ctx.saved_tensors
+        act, slope, has_bias, has_init = ctx.meta
+        if act == ACT_ELU:
+            g = g * torch.where(out > 0, torch.ones_like(out), out + 1.0)
+        elif act == ACT_LEAKY:
+            g = g * torch.where(out > 0, torch.ones_like(out), torch.full_like(out, slope))
+        ga = gw = gb = gi = None
+        if a.dim() == 3:
+            hb, m, _ = a.shape
+            g3 = g.view(m, hb, -1).permute(1, 0, 2)
+            if ctx.needs_input_grad[0]:
+                ga = torch.bmm(g3, w.transpose(1, 2))
+            if ctx.needs_input_grad[1]:
+                gw = torch.bmm(a.transpose(1, 2), g3)
+        else:
+            if ctx.needs_input_grad[0]:
+                ga = g @ w.t()
+            if ctx.needs_input_grad[1]:
+                gw = a.t() @ g
+        if has_bias and ctx.needs_input_grad[2]:
+            gb = g.sum(0)
+        if has_init and ctx.needs_input_grad[3]:
+            gi = g
+        return ga, gw, gb, gi, None, None
+
+
+def linear(a, w, bias=None, init=None, act=ACT_NONE, slope=0.01):
+    """act(a @ w + bias + init); see module docstring for the batched form (bias then is [H*N])."""
+    return _Linear.apply(a, w, bias, init, act, slope)

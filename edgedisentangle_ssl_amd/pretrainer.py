@@ -15,7 +15,7 @@ import torch
 import torch.nn.functional as F
 import torch.optim as optim
 
-from . import ops, parallel, sampling
+from . import ops, ops_gemm, parallel, sampling
 from .graph import graph_of
 from .layers import FuseLayer
 from .models import MLP
@@ -230,12 +230,18 @@ class DifHeadTrainer(Trainer):
             else:
                 lin = mods[0]
                 f_in = inp.shape[1]
-                shared = F.linear(inp, lin.weight[:, :f_in], lin.bias)
-                w_h = lin.weight[:, f_in:]
+                shared = ops_gemm.linear(inp, lin.weight[:, :f_in].t(), lin.bias)
+                w_h = lin.weight[:, f_in:].t()
+                fuse_act = isinstance(mods[1], torch.nn.LeakyReLU)
                 outs = []
                 for h in heads:
-                    t = shared + F.linear(h, w_h)
-                    for m in mods[1:]:
+                    if fuse_act:    # shared + h @ W + LeakyReLU in the GEMM epilogue
+                        t = ops_gemm.linear(h, w_h, None, shared, ops_gemm.ACT_LEAKY, mods[1].negative_slope)
+                        rest = mods[2:]
+                    else:
+                        t = ops_gemm.linear(h, w_h, None, shared)
+                        rest = mods[1:]
+                    for m in rest:
                         t = m(t)
                     outs.append(F.log_softmax(t, dim=1))
             for i, pred_label in enumerate(outs):

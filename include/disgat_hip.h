@@ -122,6 +122,20 @@ int disgat_seg_grad_hx(int col_mode, const int32_t* items, int n_items, const in
                        int F, const float* otherop, int ld_other, float* gkey, int ld_gkey, int accumulate,
                        disgat_stream_t stream);
 
+/* ---- dense contractions --------------------------------------------------------------------- */
+
+/* fp32-accurate GEMM on the bf16 matrix cores (split-bf16, 6 partial products; terms = 3 keeps 3):
+ *   C[b] = act(A[b] * B[b] + bias[b] + init[b]),  A[b] = A + b*a_batch_stride: M x K fp32, row stride lda
+ *   Bt_planes: [batch][3][N][K] bf16 = hi / mid / lo parts of B^T (k contiguous), prepared by the host
+ *   bias [batch][N] or NULL; init (row stride ldi, batch stride) or NULL; C row stride ldc.
+ *   act: 0 none, 1 ELU(alpha 1), 2 leaky ReLU(slope).  N % 128 == 0, K % 32 == 0.
+ * Replaces the torch.mm / nn.Linear calls of layers.py:350, 363, 376, 398, 110, 39, 905 and
+ * models.py:538 (reference: ATen fp32 GEMM). */
+int disgat_gemm_split(const float* A, int64_t lda, int64_t a_batch_stride, const uint16_t* Bt_planes,
+                      const float* bias, const float* init, int64_t ldi, int64_t init_batch_stride, float* C,
+                      int64_t ldc, int64_t c_batch_stride, int M, int N, int K, int batch, int act,
+                      float slope, int terms, disgat_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

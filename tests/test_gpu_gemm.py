@@ -1,0 +1,58 @@
+"""The split-bf16 MFMA GEMM against float64, with hipBLASLt's fp32 GEMM as the accuracy yardstick."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _err(x, ref):
+    return float((x.double() - ref).abs().max() / ref.abs().max())
+
+
+@pytest.mark.parametrize("m,k,n", [(1000, 256, 256), (4096, 64, 512), (777, 2048, 256), (130, 32, 128)])
+def test_plain_accuracy_matches_fp32_gemm(m, k, n):
+    from edgedisentangle_ssl_amd import ops_gemm
+    g = torch.Generator(device="cuda").manual_seed(1)
+    a = torch.randn(m, k, device="cuda", generator=g) * torch.exp(torch.randn(m, 1, device="cuda", generator=g))
+    w = torch.randn(k, n, device="cuda", generator=g) * 0.1
+    ref = a.double() @ w.double()
+    got = ops_gemm.linear(a, w)
+    blas = a @ w
+    e_got, e_blas = _err(got, ref), _err(blas, ref)
+    assert e_got <= max(2.0 * e_blas, 3e-7), (e_got, e_blas)
+
+
+def test_batched_heads_bias_init_activation_and_grads():
+    from edgedisentangle_ssl_amd import ops_gemm
+    g = torch.Generator(device="cuda").manual_seed(2)
+    H, m, k, n = 8, 1500, 64, 128
+    z = torch.randn(m, H, k, device="cuda", generator=g)
+    zt = z.permute(1, 0, 2)                                   # strided [H,M,K] view, as in disga_heads
+    w = (torch.randn(H, k, n, device="cuda", generator=g) * 0.2).requires_grad_(True)
+    bias = torch.randn(H * n, device="cuda", generator=g).requires_grad_(True)
+    init = torch.randn(m, H * n, device="cuda", generator=g).requires_grad_(True)
+    zt_g = zt.detach().clone().requires_grad_(True)
+    for act, slope, fn in ((ops_gemm.ACT_ELU, 0.0, torch.nn.functional.elu),
+                           (ops_gemm.ACT_LEAKY, 0.1, lambda t: torch.nn.functional.leaky_relu(t, 0.1)),
+                           (ops_gemm.ACT_NONE, 0.0, lambda t: t)):
+        out = ops_gemm.linear(zt_g, w, bias, init, act, slope)
+        ref = fn((torch.bmm(zt.double(), w.double()) + bias.double().view(H, 1, n)).permute(1, 0, 2).reshape(m, H * n)
+                 + init.double())
+        assert _err(out, ref.detach()) < 1e-6
+        wsum = torch.randn(m, H * n, device="cuda", generator=g)
+        grads = torch.autograd.grad((out * wsum).sum(), [zt_g, w, bias, init])
+        zr = zt.detach().double().requires_grad_(True)
+        wr, br, ir = (t.detach().double().requires_grad_(True) for t in (w, bias, init))
+        refo = fn((torch.bmm(zr, wr) + br.view(H, 1, n)).permute(1, 0, 2).reshape(m, H * n) + ir)
+        rg = torch.autograd.grad((refo * wsum.double()).sum(), [zr, wr, br, ir])
+        for a_, b_ in zip(grads, rg):
+            assert _err(a_, b_) < 1e-5
+
+
+def test_fallback_shapes_use_blas():
+    from edgedisentangle_ssl_amd import ops_gemm
+    a = torch.randn(50, 16, device="cuda")
+    w = torch.randn(16, 24, device="cuda")
+    assert torch.allclose(ops_gemm.linear(a, w, act=ops_gemm.ACT_LEAKY, slope=0.01),
+                          torch.nn.functional.leaky_relu(a @ w), atol=1e-5)
