@@ -14,6 +14,13 @@
 // operands P/Q = x W (layers.py:350, 363, 376), the per-head output projections (layers.py:398,
 // 110, 39), FuseLayer's Linear (layers.py:905) and DifHead's MLP (models.py:538).
 //
+// Tried and dropped (measured on MI355X, M = 1e6): a wave-specialised persistent variant (4 loader
+// waves + 4 MFMA waves, LDS double buffer, one block per CU) ran 3-8 % slower: with the A operand
+// split on the fly the loader path (VALU split + 18 ds_writes per thread and K-step) costs about as
+// much as the 96 MFMAs and shares their SIMD issue slots; an ablation without MFMAs still needed
+// ~1.0 us per K-step.  The next step is to have producers emit pre-split bf16 planes so that
+// operands can be DMA'd into LDS (global_load_lds) with no VALU in the loop.
+//
 // Structure: 128x128 output tile per 256-thread block (4 waves as 2x2, 64x64 each = 4x4 MFMA
 // tiles of 16x16x32), BK = 32.  A is read as fp32 (coalesced float4), split in registers and
 // written to three LDS planes; B arrives pre-split and pre-transposed ([3][N][K] bf16, k

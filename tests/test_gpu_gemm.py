@@ -10,7 +10,8 @@ def _err(x, ref):
     return float((x.double() - ref).abs().max() / ref.abs().max())
 
 
-@pytest.mark.parametrize("m,k,n", [(1000, 256, 256), (4096, 64, 512), (777, 2048, 256), (130, 32, 128)])
+@pytest.mark.parametrize("m,k,n", [(1000, 256, 256), (4096, 64, 512), (777, 2048, 256), (130, 32, 128),
+                                   (70001, 256, 256), (33000, 96, 2048)])
 def test_plain_accuracy_matches_fp32_gemm(m, k, n):
     from edgedisentangle_ssl_amd import ops_gemm
     g = torch.Generator(device="cuda").manual_seed(1)
@@ -48,6 +49,23 @@ def test_batched_heads_bias_init_activation_and_grads():
         rg = torch.autograd.grad((refo * wsum.double()).sum(), [zr, wr, br, ir])
         for a_, b_ in zip(grads, rg):
             assert _err(a_, b_) < 1e-5
+
+
+def test_large_batched_with_epilogue():
+    """Many tiles, ragged M, strided batched A, every epilogue term."""
+    from edgedisentangle_ssl_amd import ops_gemm
+    g = torch.Generator(device="cuda").manual_seed(3)
+    H, m, k, n = 8, 12345, 64, 128                            # 97 M-tiles x 8 heads = 776 tiles
+    z = torch.randn(m, H, k, device="cuda", generator=g)
+    zt = z.permute(1, 0, 2)
+    w = torch.randn(H, k, n, device="cuda", generator=g) * 0.2
+    bias = torch.randn(H * n, device="cuda", generator=g)
+    init = torch.randn(m, H * n, device="cuda", generator=g)
+    out = ops_gemm.linear(zt, w, bias, init, ops_gemm.ACT_ELU)
+    ref = torch.nn.functional.elu((torch.bmm(zt.double(), w.double()) + bias.double().view(H, 1, n)).permute(1, 0, 2)
+                                  .reshape(m, H * n) + init.double())
+    assert _err(out, ref) < 1e-6
+    assert torch.equal(out, ops_gemm.linear(zt, w, bias, init, ops_gemm.ACT_ELU))      # deterministic
 
 
 def test_fallback_shapes_use_blas():
