@@ -60,6 +60,14 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void aux_att3_kernel(const AuxArgs
       for (int j = 0; j < QN; ++j) q[j] = ld4(qp + j * G * 4);
     }
   };
+  // scores of the chunk are parked in registers (lane g of a head group keeps the pairs with
+  // i % G == g) and written once per chunk as G-float (32-B for H=8) runs instead of 64 scattered
+  // 4-byte stores per head: 8x fewer store instructions and no 4-byte partial-line writes
+  constexpr int KEEP = 64 / G;
+  float keep[KEEP];
+#pragma unroll
+  for (int t = 0; t < KEEP; ++t) keep[t] = 0.f;
+  const int g = lane & (G - 1);
   auto compute = [&](const f32x4(&q)[QN], int i) {
     const int r = __builtin_amdgcn_readlane(rv, i);
     if (r != cur_r) {  // wave-uniform
@@ -74,7 +82,10 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void aux_att3_kernel(const AuxArgs
 #pragma unroll
     for (int j = 0; j < QN; ++j) acc = dot4_lrelu(a_r[j], p_r[j], q[j], acc);
     acc = group_sum<GL>(acc);
-    if (active && (lane & (G - 1)) == 0) A.out[(int64_t)myh * A.M + m0 + i] = acc;
+    const bool mine = (i & (G - 1)) == g;
+    const int slot = i >> GL;
+#pragma unroll
+    for (int t = 0; t < KEEP; ++t) keep[t] = (mine && slot == t) ? acc : keep[t];
   };
 
   load_q(qA, __builtin_amdgcn_readlane(cv, 0));
@@ -86,6 +97,12 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void aux_att3_kernel(const AuxArgs
     compute(qB, i + 1);
   }
   if (i < cnt) compute(qA, i);
+  if (active) {
+    float* op = A.out + (int64_t)myh * A.M + m0 + g;
+#pragma unroll
+    for (int t = 0; t < KEEP; ++t)
+      if (t * G + g < cnt) op[t * G] = keep[t];
+  }
 }
 
 // att 2: e = <P[row][h][:], x[col][:]>, coalesced x mapping (lane*4 floats), head of a lane = lane % H.

@@ -99,28 +99,26 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void bwd_alpha_kernel(const BwdAlp
 #pragma unroll
     for (int i = 0; i < XN; ++i) xv[i] = (i * 256 + xoff < A.F_in) ? ld4(xp + i * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
   };
-  auto compute = [&](const f32x4(&xv)[XN], int64_t k) {
+  // Per 64-edge batch the per-(edge, head) scalars are handled in a batch layout - lane (g', h) with
+  // g' = lane / H owns batch positions i with i % GE == g' - so that edge_e / ge_in are read and
+  // ge_out / beta written as GE-float runs instead of 4-byte scattered accesses.
+  constexpr int GE = 64 >> HL;
+  const int ge = lane >> HL;
+  float galk[H];                                     // galpha of the positions this lane owns
+  auto compute = [&](const f32x4(&xv)[XN], int i) {
     float gal = 0.f;
 #pragma unroll
     for (int hh = 0; hh < H; ++hh) {
       float acc = 0.f;
 #pragma unroll
-      for (int i = 0; i < XN; ++i) acc = dot4(gz[hh * XN + i], xv[i], acc);
+      for (int t = 0; t < XN; ++t) acc = dot4(gz[hh * XN + t], xv[t], acc);
       acc = group_sum<6>(acc);
       gal = (myh == hh) ? acc : gal;
     }
-    if (lane < H) {
-      const int64_t o = (int64_t)myh * A.E + k;
-      const float e = A.edge_e[o];
-      const float s = sigmoidf_(e);
-      const float alpha = expf(s) * inv;
-      const float cf = scs * drop_mult(A.drop, k, myh, H);   // Z = sum_k alpha_k * cf_k * x[col_k]
-      const float gs = alpha * (cf * gal - tsel);
-      float g = gs * s * (1.0f - s);
-      if (A.ge_in != nullptr) g += A.ge_in[o];
-      A.ge_out[o] = g;
-      A.beta[o] = alpha * cf;
-    }
+    const bool mine = (i & (GE - 1)) == ge;
+    const int slot = i / GE;
+#pragma unroll
+    for (int t = 0; t < H; ++t) galk[t] = (mine && slot == t) ? gal : galk[t];
   };
   for (int kbase = kb; kbase < ke; kbase += 64) {
     const int cnt = min(64, ke - kbase);
@@ -129,11 +127,28 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void bwd_alpha_kernel(const BwdAlp
     int i = 0;
     for (; i + 1 < cnt; i += 2) {
       load_x(xB, __builtin_amdgcn_readlane(cv, i + 1));
-      compute(xA, (int64_t)kbase + i);
+      compute(xA, i);
       if (i + 2 < cnt) load_x(xA, __builtin_amdgcn_readlane(cv, i + 2));
-      compute(xB, (int64_t)kbase + i + 1);
+      compute(xB, i + 1);
     }
-    if (i < cnt) compute(xA, (int64_t)kbase + i);
+    if (i < cnt) compute(xA, i);
+#pragma unroll
+    for (int t = 0; t < H; ++t) {
+      const int idx = t * GE + ge;
+      if (idx < cnt) {
+        const int64_t k = (int64_t)kbase + idx;
+        const int64_t o = (int64_t)myh * A.E + k;
+        const float e = A.edge_e[o];
+        const float s = sigmoidf_(e);
+        const float alpha = expf(s) * inv;
+        const float cf = scs * drop_mult(A.drop, k, myh, H);   // Z = sum_k alpha_k * cf_k * x[col_k]
+        const float gs = alpha * (cf * galk[t] - tsel);
+        float g = gs * s * (1.0f - s);
+        if (A.ge_in != nullptr) g += A.ge_in[o];
+        A.ge_out[o] = g;
+        A.beta[o] = alpha * cf;
+      }
+    }
   }
 }
 
