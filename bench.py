@@ -261,12 +261,21 @@ def main():
         d[0] += nbytes
         d[1] += s.elapsed_time(e) * 1e-3
         d[2] += 1
+    traffic = {}
+    try:        # PMC-derived HBM bytes per launch, measured separately with rocprofv3 and committed
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        w = tj["workload"]
+        if (w["nodes"], w["edges"], w["feat"], w["heads"], w["att"], w["gnn_type"], w["n_gpus"]) == \
+                (o.nodes, o.edges, o.feat, o.heads, o.att, o.gnn_type, world) and not o.fwd_only:
+            traffic = tj["bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
     roof = None
     if agg:
         label, (b, sec, cnt) = max(agg.items(), key=lambda kv: kv[1][1])
         ach = b / sec / 1e9
         roof = {"bound": "hbm", "kernel": label, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "launches": cnt,
+                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic.get(label), "launches": cnt,
                 "avg_launch_ms": round(sec / cnt * 1e3, 3), "algorithmic_bytes_per_launch": int(b / cnt),
                 "all_kernels": {k: {"GB/s": round(v[0] / v[1] / 1e9, 1), "ms_total": round(v[1] * 1e3, 2), "launches": v[2]}
                                 for k, v in agg.items()}}
