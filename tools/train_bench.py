@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Forward+backward+Adam timing of the three SSL train_steps on a synthetic power-law graph."""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from edgedisentangle_ssl_amd import ops  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--nodes", type=int, default=200_000)
+ap.add_argument("--edges", type=int, default=4_000_000)
+ap.add_argument("--feat", type=int, default=256)
+ap.add_argument("--att", type=int, default=3)
+ap.add_argument("--gnn_type", default="AT")
+ap.add_argument("--dropout", type=float, default=0.1)
+a = ap.parse_args()
+sys.argv = ["bench.py", "--nodes", str(a.nodes), "--edges", str(a.edges), "--feat", str(a.feat), "--att", str(a.att),
+            "--gnn_type", a.gnn_type]
+o = bench.parse()
+dev = torch.device("cuda")
+args, enc, (sup, dis, dif), graph, x, lists = bench.build_workload(o, 0, 1, dev)
+for m in list(enc.modules()):
+    if hasattr(m, "dropout"):
+        m.dropout = a.dropout
+(si, sl), (hi, hl), (ti, tl) = lists
+data = (x, graph)
+
+
+def fwd_only():
+    with torch.no_grad():
+        return sup.loss(data, sl, [si]) + dis.loss(data, [hl, tl], [hi, ti]) + dif.loss(data)
+
+
+def train():
+    out = []
+    for tr, fn in ((sup, lambda: sup.loss(data, sl, [si])), (dis, lambda: dis.loss(data, [hl, tl], [hi, ti])),
+                   (dif, lambda: dif.loss(data))):
+        tr._begin_step()
+        loss = fn()
+        tr._finish_step(loss, graph)
+        out.append(loss.detach())
+    return out
+
+
+for name, fn in (("forward only (eval)", fwd_only), ("train (fwd+bwd+Adam, dropout %.2f)" % a.dropout, train)):
+    fn()
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    n = 3
+    for _ in range(n):
+        r = fn()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t) / n
+    print(f"{name:44s} {dt * 1e3:9.2f} ms/iter  {graph.nnz / dt:.3e} edges/s   peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
