@@ -105,15 +105,20 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void aux_att3_kernel(const AuxArgs
   }
 }
 
-// att 2: e = <P[row][h][:], x[col][:]>, coalesced x mapping (lane*4 floats), head of a lane = lane % H.
+// att 2: e = <P[row][h][:], x[col][:]>, coalesced x mapping (lane*4 floats); the H dot products of a
+// pair are reduced together (multi_reduce) into head groups of G lanes, scores parked like att 3.
 template <int HL, int XN>
 __global__ __launch_bounds__(DISGAT_BLOCK, 2) void aux_att2_kernel(const AuxArgs A) {
   constexpr int H = 1 << HL;
+  constexpr int GL = 6 - HL;
+  constexpr int G = 1 << GL;
   const int lane = threadIdx.x & 63;
   const int64_t m0 = ((int64_t)blockIdx.x * DISGAT_WAVES_PER_BLOCK + (threadIdx.x >> 6)) * 64;
   if (m0 >= A.M) return;
   const int cnt = (int)min((int64_t)64, A.M - m0);
-  const int myh = lane & (H - 1);
+  const int myh = lane >> GL;
+  const int g = lane & (G - 1);
+  const bool active = (myh >= A.h_lo) && (myh < A.h_hi);
   const int xoff = lane * 4;
   const int rv = (lane < cnt) ? (int)A.pr[m0 + lane] : 0;
   const int cv = (lane < cnt) ? (int)A.pc[m0 + lane] : 0;
@@ -121,6 +126,10 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void aux_att2_kernel(const AuxArgs
 #pragma unroll
   for (int j = 0; j < H * XN; ++j) p_r[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   int cur_r = -1;
+  constexpr int KEEP = 64 / G;
+  float keep[KEEP];
+#pragma unroll
+  for (int t = 0; t < KEEP; ++t) keep[t] = 0.f;
 
   auto load_x = [&](f32x4(&xv)[XN], int c) {
     const float* xp = A.x + (size_t)c * A.ldx + xoff;
@@ -142,17 +151,19 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void aux_att2_kernel(const AuxArgs
           }
         }
     }
-    float e = 0.f;
+    float part[H];
 #pragma unroll
-    for (int hh = 0; hh < H; ++hh)
-      if (hh >= A.h_lo && hh < A.h_hi) {
-        float acc = 0.f;
+    for (int hh = 0; hh < H; ++hh) {
+      float acc = 0.f;
 #pragma unroll
-        for (int t = 0; t < XN; ++t) acc = dot4(p_r[hh * XN + t], xv[t], acc);
-        acc = group_sum<6>(acc);
-        e = (myh == hh) ? acc : e;
-      }
-    if (lane < H && myh >= A.h_lo && myh < A.h_hi) A.out[(int64_t)myh * A.M + m0 + i] = e;
+      for (int t = 0; t < XN; ++t) acc = dot4(p_r[hh * XN + t], xv[t], acc);   // unscored heads keep p_r = 0
+      part[hh] = acc;
+    }
+    const float e = multi_reduce<HL>(part);
+    const bool mine = (i & (G - 1)) == g;
+    const int slot = i >> GL;
+#pragma unroll
+    for (int t = 0; t < KEEP; ++t) keep[t] = (mine && slot == t) ? e : keep[t];
   };
 
   load_x(xA, __builtin_amdgcn_readlane(cv, 0));
@@ -164,6 +175,12 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void aux_att2_kernel(const AuxArgs
     compute(xB, i + 1);
   }
   if (i < cnt) compute(xA, i);
+  if (active) {
+    float* op = A.out + (int64_t)myh * A.M + m0 + g;
+#pragma unroll
+    for (int t = 0; t < KEEP; ++t)
+      if (t * G + g < cnt) op[t * G] = keep[t];
+  }
 }
 
 // att 1: e = s1[row][h] + s2[col][h]; one thread per pair, head loop inside (writes coalesced per head).

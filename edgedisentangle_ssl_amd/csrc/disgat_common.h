@@ -35,6 +35,56 @@ __device__ __forceinline__ float group_sum(float v) {
   return v;
 }
 
+// Transposed multi-value reduction: every lane holds H = 2^HL partial sums v[0..H-1]; afterwards the
+// lanes of head group h = lane >> (6-HL) all hold the full 64-lane sum of v[h].  Each butterfly step
+// halves the number of live values: a lane keeps the half its lane bit selects and adds its
+// partner's partial of the same values, so H values cost H-1 exchanges plus the (6-HL) in-group
+// steps instead of H full reductions.  All exchanges stay on the VALU (no LDS round trips, which
+// made a ds_bpermute version slower than H independent DPP reductions): gfx950's
+// v_permlane32_swap / v_permlane16_swap do the 32- and 16-lane steps without selects; the 8- and
+// 4-lane steps pair lane i with its mirror in the 16- / 8-lane row (DPP), any partner with the
+// opposite lane bit works.
+__device__ __forceinline__ float swap_add32(float a, float b) {   // lower half: a + a[lane+32]; upper: b + b[lane-32]
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float swap_add16(float a, float b) {   // even 16-rows: a + a[lane+16]; odd rows: b + b[lane-16]
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+template <int HL>
+__device__ __forceinline__ float multi_reduce(float (&v)[1 << HL]) {
+  constexpr int H = 1 << HL;
+  const int lane = threadIdx.x & 63;
+  int n = H;
+  if constexpr (HL >= 1) {
+    n >>= 1;
+#pragma unroll
+    for (int j = 0; j < (H >> 1); ++j) v[j] = swap_add32(v[j], v[(H >> 1) + j]);
+  }
+  if constexpr (HL >= 2) {
+#pragma unroll
+    for (int j = 0; j < (H >> 2); ++j) v[j] = swap_add16(v[j], v[(H >> 2) + j]);
+  }
+  if constexpr (HL >= 3) {
+    const bool up = (lane & 8) != 0;
+#pragma unroll
+    for (int j = 0; j < (H >> 3); ++j) {
+      const float keep = up ? v[(H >> 3) + j] : v[j];
+      const float send = up ? v[j] : v[(H >> 3) + j];
+      v[j] = keep + dpp_f<0x140>(send);        // row_mirror: i <-> 15-i flips lane bit 3
+    }
+  }
+  if constexpr (HL >= 4) {
+    const bool up = (lane & 4) != 0;
+    const float keep = up ? v[1] : v[0];
+    const float send = up ? v[0] : v[1];
+    v[0] = keep + dpp_f<0x141>(send);          // row_half_mirror: i <-> 7-i flips lane bit 2
+  }
+  (void)n;
+  return group_sum<6 - HL>(v[0]);
+}
+
 __device__ __forceinline__ float sigmoidf_(float e) { return 1.0f / (1.0f + expf(-e)); }
 
 // softmax numerator of the reference: exp(sigmoid(e) - shift).  sigmoid(e) is in (0,1), so no

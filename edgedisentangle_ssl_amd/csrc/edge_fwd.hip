@@ -17,7 +17,9 @@
 //   att 3: lane = (head h = lane / G, g = lane % G), G = 64/H.  Lane (h,g) owns floats
 //          h*F_out + (j*G+g)*4 .. +3 (j < QN) of the P/Q/a rows: every wave load touches H
 //          full 128-B segments (G=8), and the per-head reduction is log2(G) DPP adds.
-//   att 1/2: score head of a lane = lane % H; x[col] is read coalesced (lane*4 floats).
+//   att 2: x[col] and P[row][h][:] coalesced (lane*4 floats); the H per-head dot products are
+//          reduced together by one transposed butterfly (multi_reduce) into the same head groups.
+//   att 1: score head of a lane = lane % H, s2[col][h] gathered directly.
 #include "disgat_common.h"
 
 namespace disgat {
@@ -64,8 +66,10 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void edge_fwd_kernel(const EdgeFwd
   const int row = rfl(it.x), kb = rfl(it.y), ke = rfl(it.z), slot = rfl(it.w);
 
   // which head this lane scores, and which lane to read head hh's weight from
-  const int myh = (ATT == 3) ? (lane >> GL) : (lane & (H - 1));
-  auto head_lane = [](int hh) { return (ATT == 3) ? (hh << GL) : hh; };
+  // att 2/3: head group = lane / G (the layout the multi-value reduction / the DPP group sums leave
+  // the scores in); att 1: head = lane % H (scores are gathered directly per lane)
+  const int myh = (ATT != 1) ? (lane >> GL) : (lane & (H - 1));
+  auto head_lane = [](int hh) { return (ATT != 1) ? (hh << GL) : hh; };
   const int xoff = lane * 4;
   const int qoff = (ATT == 3) ? (myh * FQ + (lane & (G - 1)) * 4) : 0;
 
@@ -119,7 +123,7 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void edge_fwd_kernel(const EdgeFwd
   // i % GE == ge for its head) and flushed as GE-float runs: 8x fewer store instructions and no
   // 4-byte partial-line writes (those cost the aux scorer 22 % before the same change).
   constexpr int GE = 64 >> HL;                       // lanes per head
-  const int ge = (ATT == 3) ? (lane & (G - 1)) : (lane >> HL);
+  const int ge = (ATT != 1) ? (lane & (G - 1)) : (lane >> HL);
   float keep[H];
   auto compute = [&](const Buf& b, int64_t k, int i) {
     float e;
@@ -129,15 +133,15 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void edge_fwd_kernel(const EdgeFwd
       for (int j = 0; j < QN; ++j) acc = dot4_lrelu(a_r[j], p_r[j], b.q[j], acc);
       e = group_sum<GL>(acc);
     } else if constexpr (ATT == 2) {
-      e = 0.f;
+      float part[H];
 #pragma unroll
       for (int hh = 0; hh < H; ++hh) {
         float acc = 0.f;
 #pragma unroll
-        for (int i = 0; i < XN; ++i) acc = dot4(p_r[hh * XN + i], b.xv[i], acc);
-        acc = group_sum<6>(acc);
-        e = (myh == hh) ? acc : e;
+        for (int t = 0; t < XN; ++t) acc = dot4(p_r[hh * XN + t], b.xv[t], acc);
+        part[hh] = acc;
       }
+      e = multi_reduce<HL>(part);
     } else {
       e = s1r + b.s2;
     }
@@ -193,7 +197,7 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void edge_fwd_kernel(const EdgeFwd
       for (int i = 0; i < XN; ++i)
         if (i * 256 + xoff < A.F_in) st4(zp + hh * A.F_in + i * 256, zacc[hh * XN + i] * sc);
     }
-    if (A.den != nullptr && ((ATT == 3) ? ((lane & (G - 1)) == 0) : (lane < H))) {
+    if (A.den != nullptr && ((ATT != 1) ? ((lane & (G - 1)) == 0) : (lane < H))) {
       A.den[(size_t)row * (2 * H) + myh] = den;
       A.den[(size_t)row * (2 * H) + H + myh] = dsum;
     }
@@ -204,7 +208,7 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void edge_fwd_kernel(const EdgeFwd
 #pragma unroll
       for (int i = 0; i < XN; ++i)
         if (i * 256 + xoff < A.F_in) st4(zp + hh * A.F_in + i * 256, zacc[hh * XN + i]);
-    if ((ATT == 3) ? ((lane & (G - 1)) == 0) : (lane < H)) {
+    if ((ATT != 1) ? ((lane & (G - 1)) == 0) : (lane < H)) {
       A.part_den[(size_t)slot * (2 * H) + myh] = den;
       A.part_den[(size_t)slot * (2 * H) + H + myh] = dsum;
     }
