@@ -280,7 +280,7 @@ def main():
                 "all_kernels": {k: {"GB/s": round(v[0] / v[1] / 1e9, 1), "ms_total": round(v[1] * 1e3, 2), "launches": v[2]}
                                 for k, v in agg.items()}}
     cpu = None
-    if not o.no_cpu_baseline:
+    if not o.no_cpu_baseline and world == 1:          # rank 0, N=1 only (bench contract)
         cpu = cpu_baseline(o)
     ms = dt / o.steps * 1e3
     what = "T_fwd(get_em)" if o.fwd_only else "T_iter(SupEdge+DisEdge+DifHead fwd+loss)"

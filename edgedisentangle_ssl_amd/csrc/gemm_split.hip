@@ -18,8 +18,11 @@
 // waves + 4 MFMA waves, LDS double buffer, one block per CU) ran 3-8 % slower: with the A operand
 // split on the fly the loader path (VALU split + 18 ds_writes per thread and K-step) costs about as
 // much as the 96 MFMAs and shares their SIMD issue slots; an ablation without MFMAs still needed
-// ~1.0 us per K-step.  The next step is to have producers emit pre-split bf16 planes so that
-// operands can be DMA'd into LDS (global_load_lds) with no VALU in the loop.
+// ~1.0 us per K-step.  A DMA-staged variant (global_load_lds into a 3-stage ring, counted vmcnt across
+// raw barriers, A split from its LDS fragments, 4 or 8 waves per block, one block per CU) was correct
+// but reached only 114-167 TFLOP/s against this kernel's 147-187.  For scale: the 6-product scheme's
+// ceiling is 417 TFLOP/s at the nominal MFMA rate, ~330 at the clock bf16 MFMA loops hold on random
+// data, and the guide's hand-tuned 8-phase bf16 GEMM sustains ~55 % of peak, i.e. ~230 TFLOP/s here.
 //
 // Structure: 128x128 output tile per 256-thread block (4 waves as 2x2, 64x64 each = 4x4 MFMA
 // tiles of 16x16x32), BK = 32.  A is read as fp32 (coalesced float4), split in registers and
@@ -69,6 +72,13 @@ __device__ __forceinline__ void split1(float v, uint32_t& h, uint32_t& m, uint32
 }
 
 // two bf16 (upper halves of a and b) -> one dword, a in the low half
+// Epilogue activation, branch-free (a per-element expm1f call drags a branchy libm body into every
+// unrolled store): 0 none, 1 ELU(alpha 1) with exp(v)-1 (absolute error ~1e-7), 2 leaky ReLU.
+__device__ __forceinline__ float act_fn(float v, int act, float slope) {
+  const float neg = (act == 1) ? (__expf(v) - 1.0f) : ((act == 2) ? slope * v : v);
+  return v > 0.f ? v : neg;
+}
+
 // LDS element offset of 16-B chunk `c` (0..3) of tile row `r`: chunk index XOR-swizzled with
 // (r >> 1) & 3, which makes the 16-row x 16-B MFMA fragment reads conflict-free for all four lane
 // groups of ds_read_b128 (unswizzled 64-B rows are 2-way conflicted) without padding.
@@ -233,13 +243,8 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs G) {
       if (row < G.M) {
         f32x4 v = *reinterpret_cast<const f32x4*>(&stage[lr * SLD + c4]) + bv;
         if (init) v += ld4(init + (int64_t)row * G.ldi + col);
-        if (G.act == 1) {
-          v.x = v.x > 0.f ? v.x : expm1f(v.x); v.y = v.y > 0.f ? v.y : expm1f(v.y);
-          v.z = v.z > 0.f ? v.z : expm1f(v.z); v.w = v.w > 0.f ? v.w : expm1f(v.w);
-        } else if (G.act == 2) {
-          v.x = v.x > 0.f ? v.x : G.slope * v.x; v.y = v.y > 0.f ? v.y : G.slope * v.y;
-          v.z = v.z > 0.f ? v.z : G.slope * v.z; v.w = v.w > 0.f ? v.w : G.slope * v.w;
-        }
+        v.x = act_fn(v.x, G.act, G.slope); v.y = act_fn(v.y, G.act, G.slope);
+        v.z = act_fn(v.z, G.act, G.slope); v.w = act_fn(v.w, G.act, G.slope);
         st4(C + (int64_t)row * G.ldc + col, v);
       }
     }

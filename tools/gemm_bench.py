@@ -28,7 +28,7 @@ for name, ashape, wshape, hb in cases:
         flops = 2.0 * ashape[0] * ashape[1] * wshape[1]
         blas = lambda: a @ w
     res = {}
-    for md in ("blas", "split6", "split3"):
+    for md in ("blas", "split6"):
         os.environ["DISGAT_GEMM"] = md
         fn = blas if md == "blas" else (lambda: ops_gemm._forward(a, w, None, None, 0, 0.0))
         ms = timeit(fn, 5)
