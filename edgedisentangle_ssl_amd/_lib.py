@@ -36,9 +36,22 @@ def _stale():
 
 
 def build(force=False, verbose=False):
-    """Compile every HIP source for gfx950 and link libdisgat_hip.so in-tree."""
+    """Compile every HIP source for gfx950 and link libdisgat_hip.so in-tree.  Serialised across
+    processes with a file lock (N ranks of one node import the package at the same time)."""
     if not force and not _stale():
         return LIB_PATH
+    import fcntl
+    with open(os.path.join(_HERE, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not _stale():      # another process built it while we waited
+                return LIB_PATH
+            return _build_locked(verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(verbose):
     hipcc = _hipcc()
     objdir = os.path.join(_HERE, "build")
     os.makedirs(objdir, exist_ok=True)

@@ -17,6 +17,8 @@ preprocessed once per adjacency tensor into
   t_ptr/t_src/t_eid                   the transposed structure (CSC) with the forward edge
                                       id of every entry - gather-only backward passes.
 """
+import weakref
+
 import torch
 
 
@@ -125,19 +127,24 @@ class CSRGraph:
         return self._transpose
 
 
-_GRAPH_CACHE = {}
+_GRAPH_CACHE = {}      # id(adj tensor object) -> (weakref to that object, CSRGraph)
 
 
 def graph_of(adj):
-    """CSRGraph for an adjacency tensor, cached on (storage pointer, nnz, shape, device)."""
+    """CSRGraph for an adjacency tensor, built once per tensor OBJECT (the reference hands the same
+    `adj` to every call, main.py:272-345).  Entries hold a weak reference and are validated by
+    identity, so a freed tensor whose storage address gets recycled for another graph can never
+    alias a stale CSR; they disappear when the tensor is collected."""
     if isinstance(adj, CSRGraph):
         return adj
-    idx = adj._indices()
-    key = (idx.data_ptr(), int(idx.shape[1]), int(adj.shape[0]), str(adj.device))
-    g = _GRAPH_CACHE.get(key)
-    if g is None:
-        if len(_GRAPH_CACHE) > 16:
-            _GRAPH_CACHE.clear()
-        g = CSRGraph.from_adj(adj)
-        _GRAPH_CACHE[key] = g
+    key = id(adj)
+    hit = _GRAPH_CACHE.get(key)
+    if hit is not None and hit[0]() is adj:
+        return hit[1]
+    g = CSRGraph.from_adj(adj)
+    try:
+        ref = weakref.ref(adj, lambda _r, k=key: _GRAPH_CACHE.pop(k, None))
+    except TypeError:          # not weak-referenceable: do not cache
+        return g
+    _GRAPH_CACHE[key] = (ref, g)
     return g

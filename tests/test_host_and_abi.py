@@ -123,3 +123,18 @@ def test_cpu_tensors_are_refused():
     fus = [pkg.FuseLayer(a, 4, nfeat=16), pkg.FuseLayer(a, 4, nfeat=16)]
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         enc.get_em(ic.features(21, n, 16), adj, fus)
+
+
+def test_graph_cache_is_per_tensor_object():
+    from edgedisentangle_ssl_amd.graph import graph_of, _GRAPH_CACHE
+    import gc
+    idx, vals, n = ic.tiny_graph()
+    a1 = torch.sparse_coo_tensor(idx, vals, (n, n))
+    g1 = graph_of(a1)
+    assert graph_of(a1) is g1                                 # same object -> cached
+    a2 = torch.sparse_coo_tensor(idx[:, :50], vals[:50], (n, n))
+    assert graph_of(a2) is not g1 and graph_of(a2).nnz != g1.nnz
+    key = id(a1)
+    del a1
+    gc.collect()
+    assert key not in _GRAPH_CACHE                            # entry dies with the tensor
