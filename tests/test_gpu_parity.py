@@ -163,3 +163,21 @@ def test_library_is_the_path(dev):
     fus = [pkg.FuseLayer(a, 4, nfeat=16), pkg.FuseLayer(a, 4, nfeat=16)]
     with pytest.raises(RuntimeError):
         enc.get_em(ic.features(21, n, 16), adj, fus)
+
+
+def test_launchers_reject_bad_arguments(dev):
+    """Argument errors surface as RuntimeError with the library's message; nothing is launched."""
+    from edgedisentangle_ssl_amd import _lib, ops
+    from edgedisentangle_ssl_amd.graph import CSRGraph
+    idx, vals, n = ic.tiny_graph()
+    g = CSRGraph.from_index(idx.to(dev), n)
+    x = torch.randn(n, 16, device=dev)
+    p = torch.randn(n, 3 * 64, device=dev)
+    with pytest.raises(RuntimeError, match="power of two"):
+        ops.edge_forward(g, 3, 3, 16, 64, x, p, p, torch.randn(3 * 64, device=dev), False)
+    with pytest.raises(RuntimeError, match="multiple"):
+        ops.edge_forward(g, 3, 4, 16, 40, x, p, p, torch.randn(160, device=dev), False)
+    with pytest.raises(RuntimeError, match="not in 1..3"):
+        _lib.call("disgat_edge_fwd", 7, 0, 0, 0, 0, 1, 4, 16, 64, 0, 16, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.0, 0, 0)
+    with pytest.raises(RuntimeError, match="int64 device tensor"):
+        ops.aux_forward(3, 4, 16, 64, torch.zeros(2, 5, dtype=torch.int32, device=dev), n, x, p, p, p[0], 0, 4)
