@@ -181,3 +181,19 @@ def test_launchers_reject_bad_arguments(dev):
         _lib.call("disgat_edge_fwd", 7, 0, 0, 0, 0, 1, 4, 16, 64, 0, 16, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.0, 0, 0)
     with pytest.raises(RuntimeError, match="int64 device tensor"):
         ops.aux_forward(3, 4, 16, 64, torch.zeros(2, 5, dtype=torch.int32, device=dev), n, x, p, p, p[0], 0, 4)
+
+
+def test_hip_graph_replay_equals_eager(golden_dir, dev):
+    from edgedisentangle_ssl_amd.capture import capture_get_em
+    x, adj, n, ei, sup, ho, he = real_inputs(golden_dir, "cora", dev)
+    a, enc, fus = build("AT", 3, 8, 64, x.shape[1], 203, dev)
+    with torch.no_grad():
+        eager = [t.clone() for t in enc.get_em(x, adj, fus)]
+    cap = capture_get_em(enc, x.clone(), adj, fus)
+    out = cap(x)
+    assert all(torch.equal(a_, b_) for a_, b_ in zip(out, eager))
+    x2 = x * 1.5
+    with torch.no_grad():
+        eager2 = enc.get_em(x2, adj, fus)
+    out2 = cap(x2)
+    assert all(torch.allclose(a_, b_, atol=1e-6) for a_, b_ in zip(out2, eager2))
