@@ -154,13 +154,14 @@ def _pack_score_operands(layers, x, x_all, att, H, Hp, f_in, f_out):
             a_vec.contiguous(), fp)
 
 
-def disga_heads(layers, x, adj, aux_indices=None, head_ranges=None):
+def disga_heads(layers, x, adj, aux_indices=None, head_ranges=None, aux_only=False):
     """All H heads of one DISGAT layer: the loop of models.py:225-228 as ONE fused edge pass.
 
     layers: the H DisGALayer modules (parameter holders).  adj: torch sparse COO or CSRGraph.
     aux_indices: optional list of int64 (2,M_l) pair lists (layers.py:341).  head_ranges:
     optional list of (lo,hi) per aux list restricting which heads are scored on it (DisEdge uses
     half the heads per list, pretrainer.py:619-620); unscored heads' entries are None.
+    aux_only: score the aux pairs only (no edge pass, no aggregation): returns (None, None, aux).
     Returns (HeadList of elu(h') [N,F_out], [edge_e[E,1]]*H, [[aux_e[M_l,1]]_l]*H or None).
     """
     l0 = layers[0]
@@ -189,31 +190,33 @@ def disga_heads(layers, x, adj, aux_indices=None, head_ranges=None):
     xg = x_all if (f_in_p == f_in and x_all.is_contiguous()) else F.pad(x_all, (0, f_in_p - f_in)).contiguous()
 
     rowop, colop, a_vec, f_out_p = _pack_score_operands(layers, x, x_all, att, H, Hp, f_in, f_out)
-    cfg = (graph, att, Hp, f_in_p, f_out_p, gnn == "SAGE", drop)
-    z, edge_e, _den = ops.EdgePass.apply(xg, rowop, colop, a_vec, cfg)
+    heads = e_list = None
+    if not aux_only:
+        cfg = (graph, att, Hp, f_in_p, f_out_p, gnn == "SAGE", drop)
+        z, edge_e, _den = ops.EdgePass.apply(xg, rowop, colop, a_vec, cfg)
 
-    # ---- per-head output projection on the aggregated neighbourhood (dense, MFMA), written
-    # straight into the fused [N, H*F_out] layout the fuser consumes (no torch.cat of heads)
-    zt = z[:, :H, :f_in].permute(1, 0, 2)                               # [H,N,F_in] strided view
-    concat = all(l.concat for l in layers)
-    act_code = ops_gemm.ACT_ELU if concat else ops_gemm.ACT_NONE         # ELU fused in the GEMM epilogue
-    if gnn == "AT":                                                      # layers.py:397-399
-        w = torch.stack([l.W_em for l in layers])                        # [H,F_in,F_out]
-        fused = ops_gemm.linear(zt, w, None, None, act_code)
-    elif gnn == "SAGE":                                                  # layers.py:96-110
-        wx = torch.cat([l.ag_layer.proj.weight[:, :f_in].t() for l in layers], dim=1)   # [F_in, H*F_out]
-        wn = torch.stack([l.ag_layer.proj.weight[:, f_in:].t() for l in layers])        # [H,F_in,F_out]
-        fused = ops_gemm.linear(zt, wn, None, ops_gemm.linear(x, wx), act_code)
-    else:                                                                # layers.py:38-54
-        w = torch.stack([l.ag_layer.weight for l in layers])
-        b = torch.cat([l.ag_layer.bias for l in layers])                 # [H*F_out]
-        fused = ops_gemm.linear(zt, w, b, None, act_code)
-    act = fused if concat else F.elu(fused)                              # layers.py:508-509
-    heads = HeadList(act[:, h * f_out:(h + 1) * f_out] for h in range(H))
-    heads.fused = act
-    heads.pre_elu = None if concat else [fused[:, h * f_out:(h + 1) * f_out] for h in range(H)]
+        # ---- per-head output projection on the aggregated neighbourhood (dense, MFMA), written
+        # straight into the fused [N, H*F_out] layout the fuser consumes (no torch.cat of heads)
+        zt = z[:, :H, :f_in].permute(1, 0, 2)                               # [H,N,F_in] strided view
+        concat = all(l.concat for l in layers)
+        act_code = ops_gemm.ACT_ELU if concat else ops_gemm.ACT_NONE         # ELU fused in the GEMM epilogue
+        if gnn == "AT":                                                      # layers.py:397-399
+            w = torch.stack([l.W_em for l in layers])                        # [H,F_in,F_out]
+            fused = ops_gemm.linear(zt, w, None, None, act_code)
+        elif gnn == "SAGE":                                                  # layers.py:96-110
+            wx = torch.cat([l.ag_layer.proj.weight[:, :f_in].t() for l in layers], dim=1)   # [F_in, H*F_out]
+            wn = torch.stack([l.ag_layer.proj.weight[:, f_in:].t() for l in layers])        # [H,F_in,F_out]
+            fused = ops_gemm.linear(zt, wn, None, ops_gemm.linear(x, wx), act_code)
+        else:                                                                # layers.py:38-54
+            w = torch.stack([l.ag_layer.weight for l in layers])
+            b = torch.cat([l.ag_layer.bias for l in layers])                 # [H*F_out]
+            fused = ops_gemm.linear(zt, w, b, None, act_code)
+        act = fused if concat else F.elu(fused)                              # layers.py:508-509
+        heads = HeadList(act[:, h * f_out:(h + 1) * f_out] for h in range(H))
+        heads.fused = act
+        heads.pre_elu = None if concat else [fused[:, h * f_out:(h + 1) * f_out] for h in range(H)]
 
-    e_list = [edge_e[h].unsqueeze(1) for h in range(H)]
+        e_list = [edge_e[h].unsqueeze(1) for h in range(H)]
 
     aux_out = None
     if aux_indices is not None:

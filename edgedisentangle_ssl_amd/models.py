@@ -20,6 +20,10 @@ class DISGAT(nn.Module):
         self.nheads = nheads
         self.gnn_type = args.gnn_type
         self.is_specific = is_specific
+        # predict_adjs_sparse returns only the aux scores; the reference nevertheless aggregates layer 2
+        # and runs its fuser, then discards both (models.py:319-330).  Set True to skip that unobservable
+        # work (outputs, gradients and losses are unchanged; off by default so timings compare like with like).
+        self.skip_unused = False
         self.attentions1 = [DisGALayer(nfeat, nhid, dropout=dropout, alpha=alpha, concat=True, att_type=args.att,
                                        gnn_type=self.gnn_type) for _ in range(nheads)]
         for i, attention in enumerate(self.attentions1):
@@ -37,14 +41,17 @@ class DISGAT(nn.Module):
 
     # The five entry points of the reference share one two-layer loop (models.py:181-373);
     # `_run` is that loop, returning everything any of them needs.
-    def _run(self, x, adj, fusers, auxiliary_edges=None, head_ranges=None):
+    def _run(self, x, adj, fusers, auxiliary_edges=None, head_ranges=None, scores_only_layer2=False):
         if not isinstance(fusers, list):
             fusers = [fusers]
         x = F.dropout(x, self.dropout, training=self.training)
         h1, adj1, aux1 = disga_heads(self.attentions1, x, adj, auxiliary_edges, head_ranges)
         f1 = self.fuser1(h1, x) if not self.is_specific[0] else fusers[0](h1, x)
         feature_1 = F.dropout(f1, self.dropout, training=self.training)
-        h2, adj2, aux2 = disga_heads(self.attentions2, feature_1, adj, auxiliary_edges, head_ranges)
+        h2, adj2, aux2 = disga_heads(self.attentions2, feature_1, adj, auxiliary_edges, head_ranges,
+                                     aux_only=scores_only_layer2)
+        if scores_only_layer2:
+            return dict(x=x, feature_1=feature_1, x2=None, heads=(h1, None), adjs=(adj1, None), aux=(aux1, aux2))
         f2 = self.fuser2(h2, feature_1) if not self.is_specific[1] else fusers[1](h2, feature_1)
         return dict(x=x, feature_1=feature_1, x2=f2, heads=(h1, h2), adjs=(adj1, adj2), aux=(aux1, aux2))
 
@@ -61,7 +68,7 @@ class DISGAT(nn.Module):
         return [r["adjs"][0], r["adjs"][1]]
 
     def predict_adjs_sparse(self, x, adj, fusers, auxiliary_edges, head_ranges=None):   # models.py:290-330
-        r = self._run(x, adj, fusers, auxiliary_edges, head_ranges)
+        r = self._run(x, adj, fusers, auxiliary_edges, head_ranges, scores_only_layer2=self.skip_unused)
         return [r["aux"][0], r["aux"][1]]
 
     def get_edge_em(self, x, adj, fusers):                               # models.py:333-373

@@ -197,3 +197,27 @@ def test_hip_graph_replay_equals_eager(golden_dir, dev):
         eager2 = enc.get_em(x2, adj, fus)
     out2 = cap(x2)
     assert all(torch.allclose(a_, b_, atol=1e-6) for a_, b_ in zip(out2, eager2))
+
+
+def test_skip_unused_layer2_is_unobservable(golden_dir, dev):
+    """predict_adjs_sparse with skip_unused=True (no layer-2 aggregation / fuser) returns the same
+    scores, the same SupEdge loss and the same parameter gradients."""
+    from test_gpu_backward import _trainers
+    x, adj, n, ei, sup, ho, he = real_inputs(golden_dir, "cora", dev)
+    a, enc, _ = build("SAGE", 3, 8, 64, x.shape[1], 203, dev)
+    sup_t, _, _ = _trainers(a, enc, 203, dev)
+    idx, lab = sup[0][:, :8000].to(dev), sup[1][:8000].to(dev)
+    res = []
+    for flag in (False, True):
+        enc.skip_unused = flag
+        for p in enc.parameters():
+            p.grad = None
+        loss = sup_t.loss((x, adj), lab, [idx])
+        loss.backward()
+        res.append((loss.item(), [None if p.grad is None else p.grad.clone() for p in enc.parameters()]))
+    enc.skip_unused = False
+    assert abs(res[0][0] - res[1][0]) <= 1e-7 * max(1.0, abs(res[0][0]))
+    for g0, g1 in zip(res[0][1], res[1][1]):
+        assert (g0 is None) == (g1 is None)
+        if g0 is not None:
+            assert torch.allclose(g0, g1, rtol=1e-5, atol=1e-8)
