@@ -183,13 +183,25 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void aux_att2_kernel(const AuxArgs
   }
 }
 
-// att 1: e = s1[row][h] + s2[col][h]; one thread per pair, head loop inside (writes coalesced per head).
+// att 1: e = s1[row][h] + s2[col][h]; one thread per pair, heads in float4 groups (writes coalesced
+// per head across the threads of a wave).  VEC4: h_lo, h_hi, ld_row, ld_col multiples of 4.
+template <bool VEC4>
 __global__ __launch_bounds__(256) void aux_att1_kernel(const AuxArgs A) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; m < A.M; m += stride) {
     const float* s1 = A.rowop + (size_t)A.pr[m] * A.ld_row;
     const float* s2 = A.colop + (size_t)A.pc[m] * A.ld_col;
-    for (int h = A.h_lo; h < A.h_hi; ++h) A.out[(int64_t)h * A.M + m] = s1[h] + s2[h];
+    if constexpr (VEC4) {
+      for (int h = A.h_lo; h < A.h_hi; h += 4) {
+        const f32x4 v = ld4(s1 + h) + ld4(s2 + h);
+        A.out[(int64_t)(h + 0) * A.M + m] = v.x;
+        A.out[(int64_t)(h + 1) * A.M + m] = v.y;
+        A.out[(int64_t)(h + 2) * A.M + m] = v.z;
+        A.out[(int64_t)(h + 3) * A.M + m] = v.w;
+      }
+    } else {
+      for (int h = A.h_lo; h < A.h_hi; ++h) A.out[(int64_t)h * A.M + m] = s1[h] + s2[h];
+    }
   }
 }
 
@@ -282,8 +294,10 @@ extern "C" int disgat_aux_score(int att, const int64_t* pair_rows, const int64_t
   const int grid = (int)grid64;
   if (att == 1) {
     DISGAT_REQUIRE(colop && ld_row >= H && ld_col >= H, "aux_score att=1: bad s1/s2");
-    const int g1 = (int)min((int64_t)8192, (M + 255) / 256);
-    hipLaunchKernelGGL(aux_att1_kernel, dim3(g1), dim3(256), 0, s, A);
+    const int g1 = (int)min((int64_t)16384, (M + 255) / 256);
+    const bool vec = (h_lo % 4 == 0) && (h_hi % 4 == 0) && (ld_row % 4 == 0) && (ld_col % 4 == 0) && aligned16(rowop) && aligned16(colop);
+    if (vec) hipLaunchKernelGGL(aux_att1_kernel<true>, dim3(g1), dim3(256), 0, s, A);
+    else hipLaunchKernelGGL(aux_att1_kernel<false>, dim3(g1), dim3(256), 0, s, A);
     return check_launch("aux_att1_kernel");
   }
   if (att == 2) {
