@@ -221,3 +221,24 @@ def test_skip_unused_layer2_is_unobservable(golden_dir, dev):
         assert (g0 is None) == (g1 is None)
         if g0 is not None:
             assert torch.allclose(g0, g1, rtol=1e-5, atol=1e-8)
+
+
+@pytest.mark.parametrize("rt", [0, 1, 2])
+def test_residue_fusers_on_gpu(dev, rt):
+    """--residue with the three residue_type variants (layers.py:885-915): DISGAT's own fusers
+    (is_specific=[False, False]) against the oracle."""
+    import edgedisentangle_ssl_amd as pkg
+    from oracle import disgat_oracle as orc
+    x, adj, n, _ = tiny_inputs(dev)
+    idx, _, _ = ic.tiny_graph()
+    ci = ic.coalesced_index_set(idx, n)
+    a = make_args("GCN", 3, 4, 16, 16, residue=True, residue_type=rt)
+    enc = ic.load_params(pkg.DISGAT(a, nfeat=16, nhid=16, nclass=16, nheads=4, dropout=0.0, is_specific=[False, False]), 321)
+    enc = enc.to(dev).eval()
+    with torch.no_grad():
+        em = enc.get_em(x, adj, [None, None])
+    sd = {k: v.detach().cpu() for k, v in enc.state_dict().items()}
+    fus = [lambda hs, r, p=sd, pre=f"fuser{k}.": orc.fuse_layer(p, hs, r, residue_type=rt, residue_dim=16, pre=pre) for k in (1, 2)]
+    ref = orc.disgat_pass(sd, x.cpu(), ci, fus, 4, 3, "GCN")
+    for l in range(2):
+        close(em[l], ref["feat"][l], what=f"residue_type {rt} layer {l}")

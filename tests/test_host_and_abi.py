@@ -138,3 +138,36 @@ def test_graph_cache_is_per_tensor_object():
     del a1
     gc.collect()
     assert key not in _GRAPH_CACHE                            # entry dies with the tensor
+
+
+def test_fuse_layer_and_mlp_variants_match_reference_goldens(golden_dir):
+    """The product's FuseLayer (all residue_type / fuse_no_relu / residue combinations) and MLP against
+    the reference's outputs (prims.npz); on CPU tensors they run their plain torch path."""
+    import os
+    from types import SimpleNamespace
+    from edgedisentangle_ssl_amd import FuseLayer, MLP
+    g = np.load(os.path.join(golden_dir, "prims.npz"))
+    feats = [torch.from_numpy(g[f"fuse_in{k}"]) for k in range(4)]
+    res = torch.from_numpy(g["fuse_res"])
+    for rt in (0, 1, 2):
+        for nr in (0, 1):
+            for ur in (0, 1):
+                a = SimpleNamespace(residue_type=rt, fuse_no_relu=bool(nr))
+                fl = ic.load_params(FuseLayer(a, 4, nfeat=8, residue=10 if ur else 0), 70 + rt)
+                with torch.no_grad():
+                    got = fl(feats, res)
+                assert np.abs(got.numpy() - g[f"fuse_rt{rt}_nr{nr}_res{ur}"]).max() < 2e-6, (rt, nr, ur)
+    mlp = ic.load_params(MLP(in_feat=8, hidden_size=6, out_size=4, layers=2), 80)
+    with torch.no_grad():
+        assert np.abs(mlp(feats[0]).numpy() - g["mlp_raw"]).max() < 2e-6
+        assert np.abs(mlp(feats[0], cls=True).numpy() - g["mlp_cls"]).max() < 2e-6
+
+
+def test_constrain_layer_gating():
+    """pretrainer.py:597, 728: 0 = both layers, 1 = second layer only, 2 = none (the reference then
+    crashes on `None * weight`; so does the mirror)."""
+    from edgedisentangle_ssl_amd.pretrainer import Trainer
+    t = object.__new__(Trainer)
+    for cl, want in ((0, [True, True]), (1, [False, True]), (2, [False, False])):
+        t.constrain_layer = cl
+        assert [t._layer_on(i) for i in range(2)] == want
