@@ -368,7 +368,7 @@ extern "C" int disgat_bwd_alpha(const int32_t* items, int n_items, const int32_t
                                 const float* den, const float* ge_in, float* ge_out, float* beta, int sage_div,
                                 float drop_p, uint64_t drop_seed, disgat_stream_t stream) {
   using namespace disgat;
-  if (n_items == 0) return 0;
+  if (n_items == 0 || E == 0) return 0;
   const int hl = ilog2_exact(H);
   DISGAT_REQUIRE(hl >= 1 && hl <= 4, "bwd_alpha: H=%d must be a power of two in [2,16]", H);
   DISGAT_REQUIRE(F_in > 0 && F_in % 4 == 0 && ldx % 4 == 0, "bwd_alpha: F_in/ldx must be multiples of 4");

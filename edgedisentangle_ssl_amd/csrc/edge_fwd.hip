@@ -309,7 +309,7 @@ extern "C" int disgat_edge_fwd(int att, const int32_t* items, int n_items, const
   const int hl = ilog2_exact(H);
   DISGAT_REQUIRE(hl >= 1 && hl <= 4, "edge_fwd: H=%d must be a power of two in [2,16]", H);
   DISGAT_REQUIRE(F_in > 0 && F_in % 4 == 0 && ldx % 4 == 0 && ldx >= F_in, "edge_fwd: F_in=%d ldx=%d must be multiples of 4", F_in, ldx);
-  DISGAT_REQUIRE(items && col && x && rowop && Z && edge_e, "edge_fwd: null pointer");
+  DISGAT_REQUIRE(items && x && rowop && Z && (E == 0 || (col && edge_e)), "edge_fwd: null pointer");   // E == 0: rows are only zero-filled
   DISGAT_REQUIRE(aligned16(items) && aligned16(x) && aligned16(Z), "edge_fwd: items/x/Z must be 16-byte aligned");
   const int xn = (F_in + 255) / 256;
   int qn = 1;

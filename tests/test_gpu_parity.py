@@ -264,7 +264,20 @@ def test_degenerate_inputs(dev, gnn, att):
             heads, e_list, aux_out = pkg.disga_heads(layers, x.to(dev), adj, [a.to(dev) for a in aux])
         for h, lay in enumerate(layers):
             sd = {k: v.detach().cpu() for k, v in lay.state_dict().items()}
-            ho, e, au = orc.disga_layer(x, idx, sd, att, gnn, aux)
+            if idx.shape[1] == 0:
+                # the reference itself cannot run on an empty edge list (values.max() of nothing, utils.py:194);
+                # the defined limit is: no neighbours -> zero aggregate
+                zero = torch.zeros(n, f)
+                if gnn == "AT":
+                    ho = torch.nn.functional.elu(zero @ sd["W_em"])
+                elif gnn == "SAGE":
+                    ho = torch.nn.functional.elu(torch.cat([x, zero], -1) @ sd["ag_layer.proj.weight"].t())
+                else:
+                    ho = torch.nn.functional.elu(zero @ sd["ag_layer.weight"] + sd["ag_layer.bias"])
+                e = torch.zeros(0, 1)
+                au = [orc.pair_score(att, x, sd["W"], sd["a"], a_[0], a_[1]) for a_ in aux]
+            else:
+                ho, e, au = orc.disga_layer(x, idx, sd, att, gnn, aux)
             close(heads[h], ho, what=f"{name}: head {h}")
             assert e_list[h].shape == (idx.shape[1], 1)
             if idx.shape[1]:
