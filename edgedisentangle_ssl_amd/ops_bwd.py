@@ -34,6 +34,8 @@ def edge_backward(ctx, gz, ge):
     need_x, need_row, need_col, need_a = ctx.needs_input_grad[:4]
     dev = x.device
     n, e = graph.n, graph.nnz
+    if e == 0:                      # no edges: Z == 0 and no score exists, every gradient is zero
+        return None, None, None, None, None
     chunk = ops.CHUNK[att]
     wi = graph.work_items(chunk)
     gz = torch.zeros_like(z) if gz is None else gz.contiguous()
@@ -90,6 +92,8 @@ def aux_backward(ctx, gout):
     att, H, f_in, f_out, n, lo, hi = ctx.cfg
     need_x, need_row, need_col, need_a = ctx.needs_input_grad[:4]
     dev = gout.device
+    if pairs.shape[1] == 0:         # empty pair list: nothing was scored
+        return None, None, None, None, None, None
     gout = gout.contiguous()
     rows, cols = pairs[0], pairs[1]
     g_x = g_row = g_col = g_a = None

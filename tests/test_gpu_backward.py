@@ -127,3 +127,20 @@ def test_cora_gradients_vs_oracle_autograd(golden_dir, dev, gnn, att, monkeypatc
         want = sd[k].grad if sd[k].grad is not None else torch.zeros_like(sd[k])
         got = p.grad if p.grad is not None else torch.zeros_like(p)
         close(got, want, tol=GTOL, what=f"grad {k}")
+
+
+def test_backward_with_empty_graph_and_empty_pair_list(dev):
+    import edgedisentangle_ssl_amd as pkg
+    n, H, f = 30, 4, 16
+    x = ic.features(78, n, f).to(dev).requires_grad_(True)
+    layers = [ic.load_params(pkg.DisGALayer(f, f, dropout=0.0, alpha=0.1, att_type=3, gnn_type="SAGE"), 710 + h).to(dev)
+              for h in range(H)]
+    adj = torch.sparse_coo_tensor(torch.zeros((2, 0), dtype=torch.int64), torch.zeros(0), (n, n)).to(dev)
+    aux = [torch.zeros((2, 0), dtype=torch.int64, device=dev), torch.tensor([[1, 2], [3, 4]], device=dev)]
+    heads, e_list, aux_out = pkg.disga_heads(layers, x, adj, aux)
+    loss = sum(h.sum() for h in heads) + sum(a[1].sum() for a in aux_out) + sum(a[0].sum() for a in aux_out)
+    loss.backward()
+    assert torch.isfinite(x.grad).all()
+    for lay in layers:
+        assert all(p.grad is None or torch.isfinite(p.grad).all() for p in lay.parameters())
+        assert lay.W.grad is not None and float(lay.W.grad.abs().sum()) > 0       # through the one scored pair list
