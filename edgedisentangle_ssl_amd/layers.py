@@ -184,8 +184,14 @@ def disga_heads(layers, x, adj, aux_indices=None, head_ranges=None, aux_only=Fal
     if Hp > 16:
         raise NotImplementedError("more than 16 heads is outside the kernel envelope")
     f_in_p = (f_in + 3) // 4 * 4
-    if f_in_p > 512 or Hp * ((f_in_p + 255) // 256) > 16:
-        raise NotImplementedError(f"kernel envelope: F_in={f_in} with {Hp} heads does not fit the register tile")
+    # register tile of the edge pass: Hp * ceil(F_in/256) float4 accumulators <= 16.  Wider inputs (raw
+    # bag-of-words features, --origin_feat) are aggregated in column slices; the scores of att 1 / 3 do
+    # not depend on x, so every slice sees identical attention weights (the scores are recomputed per
+    # slice: correct, not cheap).  att 2's score is a dot product over all of x and cannot be sliced.
+    tile = 256 * max(1, 16 // Hp) if Hp <= 16 else 0
+    tile = min(tile, 512)
+    if f_in_p > tile and att == 2:
+        raise NotImplementedError(f"kernel envelope: att=2 needs F_in <= {tile} with {Hp} heads (got {f_in})")
     x_all = parallel.all_gather_rows(x, graph)       # sharded: one exchange per layer
     xg = x_all if (f_in_p == f_in and x_all.is_contiguous()) else F.pad(x_all, (0, f_in_p - f_in)).contiguous()
 
