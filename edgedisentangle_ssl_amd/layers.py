@@ -198,8 +198,18 @@ def disga_heads(layers, x, adj, aux_indices=None, head_ranges=None, aux_only=Fal
     rowop, colop, a_vec, f_out_p = _pack_score_operands(layers, x, x_all, att, H, Hp, f_in, f_out)
     heads = e_list = None
     if not aux_only:
-        cfg = (graph, att, Hp, f_in_p, f_out_p, gnn == "SAGE", drop)
-        z, edge_e, _den = ops.EdgePass.apply(xg, rowop, colop, a_vec, cfg)
+        if f_in_p <= tile:
+            cfg = (graph, att, Hp, f_in_p, f_out_p, gnn == "SAGE", drop)
+            z, edge_e, _den = ops.EdgePass.apply(xg, rowop, colop, a_vec, cfg)
+        else:
+            zs, edge_e = [], None
+            for c0 in range(0, f_in_p, tile):
+                c1 = min(f_in_p, c0 + tile)
+                cfg = (graph, att, Hp, c1 - c0, f_out_p, gnn == "SAGE", drop)
+                zc, ec, _den = ops.EdgePass.apply(xg[:, c0:c1], rowop, colop, a_vec, cfg)
+                zs.append(zc)
+                edge_e = ec if edge_e is None else edge_e
+            z = torch.cat(zs, dim=2)
 
         # ---- per-head output projection on the aggregated neighbourhood (dense, MFMA), written
         # straight into the fused [N, H*F_out] layout the fuser consumes (no torch.cat of heads)
