@@ -120,7 +120,25 @@ class HeadList(list):
     pre_elu = None
 
 
-def _pack_score_operands(layers, x, x_all, att, H, Hp, f_in, f_out):
+def _kernel_heads(att, Hp, f_out):
+    """Heads per kernel launch (a power of two in [2,16]) and the padded per-head F_out for att 3.
+
+    The att-3 lane map gives a head G = 64/Hk lanes x QN float4 (QN <= 8), i.e. Hk * F_out_padded <= 2048
+    per launch; wider layers (more heads, wider heads) run as several head groups, each a launch over
+    its slice of the operands."""
+    hk = min(Hp, 16)
+    if att != 3:
+        return hk, f_out
+    while hk >= 2:
+        g4 = (64 // hk) * 4
+        qn = _pow2ceil((f_out + g4 - 1) // g4)
+        if qn <= 8:
+            return hk, qn * g4
+        hk //= 2
+    raise NotImplementedError(f"att=3 kernel envelope: a single head wider than 1024 features (nhid={f_out})")
+
+
+def _pack_score_operands(layers, x, x_all, att, H, Hp, f_in, f_out, fp):
     """Dense, differentiable (torch ops -> MFMA GEMMs) preparation of the per-node score operands.
     x: the rows this process owns; x_all: every node a column index can name (== x unsharded).
 
@@ -128,30 +146,24 @@ def _pack_score_operands(layers, x, x_all, att, H, Hp, f_in, f_out):
                                 with s1 = x (W a[:F]),  s2 = x (W a[F:])           -> [N,Hp] each
     att 2 (layers.py:362-365):  e = <x_r W, x_c W> = <x_r (W W^T), x_c>           -> P = x (W W^T)
     att 3 (layers.py:374-379):  e = a . lrelu([x_r || x_c] W) = a . lrelu(P[r] + Q[c]),
-                                P = x W[:F_in], Q = x W[F_in:]                     -> [N,Hp*F_out_p] each
-    Returns (rowop, colop, a_vec, F_out_padded).
+                                P = x W[:F_in], Q = x W[F_in:]                     -> [N,Hp*fp] each
+    Returns (rowop, colop, a_vec); fp = padded per-head width of the att-3 operands.
     """
     if att == 1:
         zero = [x.new_zeros(f_in)] * (Hp - H)
         w1 = torch.stack([l.W @ l.a[:f_out, 0] for l in layers] + zero, dim=1)     # [F_in, Hp]
         w2 = torch.stack([l.W @ l.a[f_out:, 0] for l in layers] + zero, dim=1)
-        return x @ w1, x_all @ w2, None, f_out                                     # N = Hp: too narrow for the MFMA tile
+        return x @ w1, x_all @ w2, None                                            # N = Hp: too narrow for the MFMA tile
     if att == 2:
         f_in_p = (f_in + 3) // 4 * 4
         ms = [F.pad(l.W @ l.W.t(), (0, f_in_p - f_in)) for l in layers]
         ms += [x.new_zeros(f_in, f_in_p)] * (Hp - H)
-        return ops_gemm.linear(x, torch.cat(ms, dim=1)), None, None, f_out          # [N, Hp*F_in_p]
-    g4 = (64 // Hp) * 4
-    qn = _pow2ceil((f_out + g4 - 1) // g4)
-    if qn > 8:
-        raise NotImplementedError(
-            f"att=3 kernel envelope: nhead*nhid must be <= 2048 after padding (got H={Hp}, F_out={f_out})")
-    fp = qn * g4
+        return ops_gemm.linear(x, torch.cat(ms, dim=1)), None, None                 # [N, Hp*F_in_p]
     tops = [F.pad(l.W[:f_in], (0, fp - f_out)) for l in layers] + [x.new_zeros(f_in, fp)] * (Hp - H)
     bots = [F.pad(l.W[f_in:], (0, fp - f_out)) for l in layers] + [x.new_zeros(f_in, fp)] * (Hp - H)
     a_vec = torch.cat([F.pad(l.a[:, 0], (0, fp - f_out)) for l in layers] + [x.new_zeros(fp)] * (Hp - H))
     return (ops_gemm.linear(x, torch.cat(tops, dim=1)), ops_gemm.linear(x_all, torch.cat(bots, dim=1)),
-            a_vec.contiguous(), fp)
+            a_vec.contiguous())
 
 
 def disga_heads(layers, x, adj, aux_indices=None, head_ranges=None, aux_only=False):
@@ -181,35 +193,53 @@ def disga_heads(layers, x, adj, aux_indices=None, head_ranges=None, aux_only=Fal
     if graph.n != x.shape[0]:
         raise ValueError("adjacency / feature row count mismatch")
     Hp = max(2, _pow2ceil(H))
-    if Hp > 16:
-        raise NotImplementedError("more than 16 heads is outside the kernel envelope")
+    Hk, fp = _kernel_heads(att, Hp, f_out)           # heads per launch; Hp / Hk head groups
+    n_groups = Hp // Hk
     f_in_p = (f_in + 3) // 4 * 4
-    # register tile of the edge pass: Hp * ceil(F_in/256) float4 accumulators <= 16.  Wider inputs (raw
+    # register tile of the edge pass: Hk * ceil(F_in/256) float4 accumulators <= 16.  Wider inputs (raw
     # bag-of-words features, --origin_feat) are aggregated in column slices; the scores of att 1 / 3 do
     # not depend on x, so every slice sees identical attention weights (the scores are recomputed per
     # slice: correct, not cheap).  att 2's score is a dot product over all of x and cannot be sliced.
-    tile = 256 * max(1, 16 // Hp) if Hp <= 16 else 0
-    tile = min(tile, 512)
+    tile = min(512, 256 * max(1, 16 // Hk))
     if f_in_p > tile and att == 2:
-        raise NotImplementedError(f"kernel envelope: att=2 needs F_in <= {tile} with {Hp} heads (got {f_in})")
+        raise NotImplementedError(f"kernel envelope: att=2 needs F_in <= {tile} with {Hk} heads per launch (got {f_in})")
     x_all = parallel.all_gather_rows(x, graph)       # sharded: one exchange per layer
     xg = x_all if (f_in_p == f_in and x_all.is_contiguous()) else F.pad(x_all, (0, f_in_p - f_in)).contiguous()
 
-    rowop, colop, a_vec, f_out_p = _pack_score_operands(layers, x, x_all, att, H, Hp, f_in, f_out)
+    rowop, colop, a_vec = _pack_score_operands(layers, x, x_all, att, H, Hp, f_in, f_out, fp)
+    # per-head operand width inside a row of rowop / colop (att 1: one scalar, att 2: F_in_p, att 3: fp)
+    w_row = {1: 1, 2: f_in_p, 3: fp}[att]
+
+    def group_ops(gi):
+        lo = gi * Hk * w_row
+        hi = lo + Hk * w_row
+        r = rowop[:, lo:hi]
+        c = None if colop is None else colop[:, lo:hi]
+        av = None if a_vec is None else a_vec[lo:hi]
+        d = (drop[0], drop[1] + 0x9E3779B1 * gi) if drop[0] > 0 else drop      # independent masks per group
+        return r, c, av, d
+
     heads = e_list = None
     if not aux_only:
-        if f_in_p <= tile:
-            cfg = (graph, att, Hp, f_in_p, f_out_p, gnn == "SAGE", drop)
-            z, edge_e, _den = ops.EdgePass.apply(xg, rowop, colop, a_vec, cfg)
-        else:
-            zs, edge_e = [], None
-            for c0 in range(0, f_in_p, tile):
-                c1 = min(f_in_p, c0 + tile)
-                cfg = (graph, att, Hp, c1 - c0, f_out_p, gnn == "SAGE", drop)
-                zc, ec, _den = ops.EdgePass.apply(xg[:, c0:c1], rowop, colop, a_vec, cfg)
-                zs.append(zc)
-                edge_e = ec if edge_e is None else edge_e
-            z = torch.cat(zs, dim=2)
+        z_groups, e_groups = [], []
+        for gi in range(n_groups):
+            r, c, av, d = group_ops(gi)
+            if f_in_p <= tile:
+                cfg = (graph, att, Hk, f_in_p, fp, gnn == "SAGE", d)
+                z, edge_e, _den = ops.EdgePass.apply(xg, r, c, av, cfg)
+            else:
+                zs, edge_e = [], None
+                for c0 in range(0, f_in_p, tile):
+                    c1 = min(f_in_p, c0 + tile)
+                    cfg = (graph, att, Hk, c1 - c0, fp, gnn == "SAGE", d)
+                    zc, ec, _den = ops.EdgePass.apply(xg[:, c0:c1], r, c, av, cfg)
+                    zs.append(zc)
+                    edge_e = ec if edge_e is None else edge_e
+                z = torch.cat(zs, dim=2)
+            z_groups.append(z)
+            e_groups.append(edge_e)
+        z = z_groups[0] if n_groups == 1 else torch.cat(z_groups, dim=1)             # [N, Hp, F_in_p]
+        edge_e = e_groups[0] if n_groups == 1 else torch.cat(e_groups, dim=0)        # [Hp, E]
 
         # ---- per-head output projection on the aggregated neighbourhood (dense, MFMA), written
         # straight into the fused [N, H*F_out] layout the fuser consumes (no torch.cat of heads)
@@ -241,9 +271,17 @@ def disga_heads(layers, x, adj, aux_indices=None, head_ranges=None, aux_only=Fal
         per_list = []
         for li, pairs in enumerate(aux_indices):
             lo, hi = (0, H) if head_ranges is None or head_ranges[li] is None else head_ranges[li]
-            acfg = (att, Hp, f_in_p, f_out_p, graph.n, lo, hi)
-            out = ops.AuxPass.apply(xg if att == 2 else None, rowop, colop, a_vec, pairs, acfg)
-            per_list.append([out[h].unsqueeze(1) if lo <= h < hi else None for h in range(H)])
+            per_head = [None] * H
+            for gi in range(n_groups):
+                g_lo, g_hi = max(lo, gi * Hk), min(hi, (gi + 1) * Hk)      # heads of this group that are scored
+                if g_lo >= g_hi:
+                    continue
+                r, c, av, _d = group_ops(gi)
+                acfg = (att, Hk, f_in_p, fp, graph.n, g_lo - gi * Hk, g_hi - gi * Hk)
+                out = ops.AuxPass.apply(xg if att == 2 else None, r, c, av, pairs, acfg)
+                for h in range(g_lo, g_hi):
+                    per_head[h] = out[h - gi * Hk].unsqueeze(1)
+            per_list.append(per_head)
         aux_out = [[per_list[li][h] for li in range(len(aux_indices))] for h in range(H)]
     return heads, e_list, aux_out
 
