@@ -120,13 +120,16 @@ class HeadList(list):
     pre_elu = None
 
 
-def _kernel_heads(att, Hp, f_out):
+def _kernel_heads(att, Hp, f_out, f_in_p=0):
     """Heads per kernel launch (a power of two in [2,16]) and the padded per-head F_out for att 3.
 
     The att-3 lane map gives a head G = 64/Hk lanes x QN float4 (QN <= 8), i.e. Hk * F_out_padded <= 2048
     per launch; wider layers (more heads, wider heads) run as several head groups, each a launch over
     its slice of the operands."""
     hk = min(Hp, 16)
+    if att == 2:                                    # the dot product over x cannot be sliced: fewer heads per
+        while hk > 2 and 256 * (16 // hk) < min(f_in_p, 512):   # launch buy a wider register tile instead
+            hk //= 2
     if att != 3:
         return hk, f_out
     while hk >= 2:
@@ -193,9 +196,9 @@ def disga_heads(layers, x, adj, aux_indices=None, head_ranges=None, aux_only=Fal
     if graph.n != x.shape[0]:
         raise ValueError("adjacency / feature row count mismatch")
     Hp = max(2, _pow2ceil(H))
-    Hk, fp = _kernel_heads(att, Hp, f_out)           # heads per launch; Hp / Hk head groups
-    n_groups = Hp // Hk
     f_in_p = (f_in + 3) // 4 * 4
+    Hk, fp = _kernel_heads(att, Hp, f_out, f_in_p)   # heads per launch; Hp / Hk head groups
+    n_groups = Hp // Hk
     # register tile of the edge pass: Hk * ceil(F_in/256) float4 accumulators <= 16.  Wider inputs (raw
     # bag-of-words features, --origin_feat) are aggregated in column slices; the scores of att 1 / 3 do
     # not depend on x, so every slice sees identical attention weights (the scores are recomputed per

@@ -19,7 +19,7 @@ CASES = [
     (1, 10, 10, 1, "AT"), (5, 300, 33, 1, "SAGE"), (16, 130, 7, 1, "GCN"), (8, 256, 64, 1, "AT"),
     (1, 12, 9, 2, "GCN"), (3, 70, 50, 2, "AT"), (8, 300, 40, 2, "SAGE"), (16, 100, 16, 2, "AT"), (4, 512, 8, 2, "GCN"),
     # more heads / wider heads than one launch covers: head groups
-    (24, 32, 40, 3, "AT"), (8, 64, 512, 3, "SAGE"), (4, 48, 1024, 3, "GCN"), (40, 20, 6, 1, "AT"), (20, 36, 12, 2, "SAGE"),
+    (24, 32, 40, 3, "AT"), (8, 64, 512, 3, "SAGE"), (4, 48, 1024, 3, "GCN"), (40, 20, 6, 1, "AT"), (20, 36, 12, 2, "SAGE"), (16, 257, 16, 2, "AT"), (32, 500, 8, 2, "GCN"),
     # wider than the register tile: aggregated in column slices (att 1 / 3 only)
     (4, 1433, 16, 3, "AT"), (8, 700, 32, 3, "SAGE"), (16, 300, 8, 1, "GCN"), (2, 1100, 24, 1, "AT"),
 ]
