@@ -1,0 +1,23 @@
+"""A slice of tools/fuzz_parity.py in the GPU suite: random graphs / heads / widths / attention and
+aggregation types / aux lists / head ranges / chunk sizes, forward + backward vs the float64 oracle."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+
+
+@pytest.mark.parametrize("seed", [10, 11])
+def test_randomised_parity(seed):
+    import fuzz_parity
+    from edgedisentangle_ssl_amd import ops
+    rng = np.random.Generator(np.random.PCG64(seed))
+    saved = dict(ops.CHUNK)
+    try:
+        results = [fuzz_parity.one(c, rng) for c in range(30)]
+    finally:
+        ops.CHUNK = saved
+    assert sum(r == "ok" for r in results) >= 20, results

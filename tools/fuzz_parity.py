@@ -63,9 +63,25 @@ def one(case, rng):
             ranges.append((lo, int(rng.integers(lo + 1, H + 1))))
     desc = f"case {case}: n={n} E={ci.shape[1]} H={H} F_in={f_in} F_out={f_out} att={att} gnn={gnn} chunk={chunk} aux={[a.shape[1] for a in aux]} ranges={ranges}"
     ops.CHUNK = {1: chunk, 2: chunk, 3: chunk}
-    x = torch.from_numpy(rng.standard_normal((n, f_in)).astype(np.float32) * 0.5)
     layers = [ic.load_params(pkg.DisGALayer(f_in, f_out, dropout=0.0, alpha=0.1, att_type=att, gnn_type=gnn), 900 + 7 * case + h)
               .to(dev).eval() for h in range(H)]
+    # att 3's leaky-ReLU has a kink at z = P[r] + Q[c] = 0: an fp32 evaluation may sit on the other side of it
+    # than the float64 oracle when |z| ~ 1e-7, which flips one gradient term (0.01 <-> 1) - a property of the
+    # function, not of the kernel.  Redraw x until no argument is that close to the kink.
+    for attempt in range(20):
+        x = torch.from_numpy(rng.standard_normal((n, f_in)).astype(np.float32) * 0.5)
+        if att != 3:
+            break
+        near = 0
+        for lay in layers:
+            w = lay.W.detach().cpu().double()
+            for r_, c_ in [(ci[0], ci[1])] + [(a_[0], a_[1]) for a_ in aux if a_.shape[1]]:
+                z = x.double()[r_] @ w[:f_in] + x.double()[c_] @ w[f_in:]
+                near += int((z.abs() < 5e-6).sum())
+        if near == 0:
+            break
+    else:
+        return "skip (could not avoid the kink)"
     adj = torch.sparse_coo_tensor(idx, torch.ones(idx.shape[1]), (n, n)).to(dev)
     xg = x.to(dev).requires_grad_(True)
     heads, e_list, aux_out = pkg.disga_heads(layers, xg, adj, [a.to(dev) for a in aux] if aux else None, ranges)
@@ -97,23 +113,7 @@ def one(case, rng):
                 close(aux_out[h][li][:, 0], au[li][:, 0], 1e-4, desc + f" aux{li} {h}")
                 ref_loss = ref_loss + (au[li][:, 0] * wa[li][h]).sum()
     ref_loss.backward()
-    # att 3's leaky-ReLU has a kink at z = P[r] + Q[c] = 0: an fp32 evaluation may sit on the other side of
-    # it than the float64 oracle when |z| ~ 1e-7, which flips one term of the gradient (0.01 <-> 1).  Count
-    # such near-kink arguments and loosen the gradient tolerance for those cases only.
     gtol = 3e-4
-    if att == 3:
-        near = 0
-        for h in range(H):
-            w = sds[h]["W"].detach()
-            z = x.double()[ci[0]] @ w[:f_in] + x.double()[ci[1]] @ w[f_in:]
-            near += int((z.abs() < 2e-6).sum())
-            for a_ in aux:
-                if a_.shape[1]:
-                    z = x.double()[a_[0]] @ w[:f_in] + x.double()[a_[1]] @ w[f_in:]
-                    near += int((z.abs() < 2e-6).sum())
-        if near:
-            gtol = 5e-2
-            desc += f" [near-kink z: {near}]"
     close(xg.grad, xc.grad, gtol, desc + " grad x")
     for h, lay in enumerate(layers):
         for k, prm in lay.named_parameters():
