@@ -94,6 +94,8 @@ def build_workload(o, rank, world, dev):
         r, c = torch.from_numpy(r).to(dev), torch.from_numpy(c).to(dev)
         loop = torch.arange(o.nodes, device=dev)
         idx = torch.stack([torch.cat([r, c, loop]), torch.cat([c, r, loop])])
+        warm = CSRGraph.from_index(idx[:, :100_000] % 4096, 4096)     # load the sort/scan kernels first: the
+        warm.work_items(ops.CHUNK[o.att])                              # first call pays ~0.8 s of one-time set-up
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         graph = CSRGraph.from_index(idx, o.nodes)
