@@ -24,20 +24,22 @@ class DISGAT(nn.Module):
         # and runs its fuser, then discards both (models.py:319-330).  Set True to skip that unobservable
         # work (outputs, gradients and losses are unchanged; off by default so timings compare like with like).
         self.skip_unused = False
-        self.attentions1 = [DisGALayer(nfeat, nhid, dropout=dropout, alpha=alpha, concat=True, att_type=args.att,
-                                       gnn_type=self.gnn_type) for _ in range(nheads)]
-        for i, attention in enumerate(self.attentions1):
-            self.add_module("attention1_{}".format(i), attention)
-        self.attentions2 = [DisGALayer(nhid, nclass, dropout=dropout, alpha=alpha, concat=True, att_type=args.att,
-                                       gnn_type=self.gnn_type) for _ in range(nheads)]
-        for i, attention in enumerate(self.attentions2):
-            self.add_module("attention2_{}".format(i), attention)
-        if args.residue:
-            self.fuser1 = FuseLayer(args, nheads, nfeat=nhid, residue=nfeat)
-            self.fuser2 = FuseLayer(args, nheads, nfeat=nhid, residue=nhid)
-        else:
-            self.fuser1 = FuseLayer(args, nheads, nfeat=nhid)
-            self.fuser2 = FuseLayer(args, nheads, nfeat=nhid)
+        # parameter creation order (= torch RNG draw order of the reference, models.py:163-179): all heads of
+        # layer 1, all heads of layer 2, then the model's own two fusers
+        self.attentions1 = self._make_heads("attention1_", nfeat, nhid, dropout, alpha, args.att)
+        self.attentions2 = self._make_heads("attention2_", nhid, nclass, dropout, alpha, args.att)
+        res = (nfeat, nhid) if args.residue else (0, 0)
+        self.fuser1 = FuseLayer(args, nheads, nfeat=nhid, residue=res[0])
+        self.fuser2 = FuseLayer(args, nheads, nfeat=nhid, residue=res[1])
+
+    def _make_heads(self, prefix, fin, fout, dropout, alpha, att):
+        """H DisGALayer heads registered as `<prefix><i>` (the reference's state_dict keys)."""
+        heads = []
+        for i in range(self.nheads):
+            head = DisGALayer(fin, fout, dropout=dropout, alpha=alpha, concat=True, att_type=att, gnn_type=self.gnn_type)
+            self.add_module(prefix + str(i), head)
+            heads.append(head)
+        return heads
 
     # The five entry points of the reference share one two-layer loop (models.py:181-373);
     # `_run` is that loop, returning everything any of them needs.

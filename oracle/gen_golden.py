@@ -105,6 +105,17 @@ def gen_prims():
     out["mlp_cls"] = np32(mlp(feats[0], cls=True))
     np.savez_compressed(os.path.join(GOLD, "prims.npz"), **out)
     print("prims.npz", len(out))
+    # initial parameters of the reference's DISGAT under torch.manual_seed(4) (RNG draw order contract)
+    init = {}
+    for gnn in GNNS:
+        for att in (1, 3):
+            a = ref_args(gnn, att, 3, 12, 20)
+            torch.manual_seed(4)
+            m = ref_models.DISGAT(a, nfeat=20, nhid=12, nclass=12, nheads=3, dropout=0.1)
+            for k, v in m.state_dict().items():
+                init[f"{gnn}_{att}.{k}"] = np32(v)
+    np.savez_compressed(os.path.join(GOLD, "init_seed4.npz"), **init)
+    print("init_seed4.npz", len(init))
 
 
 # --------------------------------------------------------------------------- one (gnn, att) case

@@ -171,3 +171,22 @@ def test_constrain_layer_gating():
     for cl, want in ((0, [True, True]), (1, [False, True]), (2, [False, False])):
         t.constrain_layer = cl
         assert [t._layer_on(i) for i in range(2)] == want
+
+
+def test_same_seed_gives_the_reference_initial_parameters(golden_dir):
+    """Parameter creation order and initialisers match the reference (models.py:163-179,
+    layers.py:319-337, 33-36, 79): torch.manual_seed(s) yields bit-identical initial state_dicts."""
+    import os
+    from types import SimpleNamespace
+    from edgedisentangle_ssl_amd import DISGAT
+    g = np.load(os.path.join(golden_dir, "init_seed4.npz"))
+    for gnn in ("AT", "SAGE", "GCN"):
+        for att in (1, 3):
+            a = SimpleNamespace(gnn_type=gnn, att=att, residue=False, residue_type=0, fuse_no_relu=False)
+            torch.manual_seed(4)
+            m = DISGAT(a, nfeat=20, nhid=12, nclass=12, nheads=3, dropout=0.1)
+            sd = m.state_dict()
+            keys = [k[len(f"{gnn}_{att}."):] for k in g.files if k.startswith(f"{gnn}_{att}.")]
+            assert keys == list(sd.keys())
+            for k in keys:
+                assert np.array_equal(sd[k].numpy(), g[f"{gnn}_{att}.{k}"]), (gnn, att, k)
