@@ -7,5 +7,5 @@ char* err_buf() {
 }
 }  // namespace disgat
 
-extern "C" int disgat_abi_version(void) { return 1; }
+extern "C" int disgat_abi_version(void) { return 2; }
 extern "C" const char* disgat_last_error(void) { return disgat::err_buf(); }

@@ -27,10 +27,11 @@ struct AuxArgs {
   int ld_col;
   const float* a;
   float* out;
+  void* sign;   // att 3, optional: [M][64] sign words for the backward pass (disgat_common.h SignWord)
 };
 
 // att 3: lane = (head, g) exactly as in edge_fwd_kernel<3,...>.
-template <int HL, int QN>
+template <int HL, int QN, bool SIGN>
 __global__ __launch_bounds__(DISGAT_BLOCK, 2) void aux_att3_kernel(const AuxArgs A) {
   constexpr int GL = 6 - HL;
   constexpr int G = 1 << GL;
@@ -79,8 +80,20 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void aux_att3_kernel(const AuxArgs
       }
     }
     float acc = 0.f;
+    if constexpr (SIGN) {
+      uint32_t bits = 0u;
 #pragma unroll
-    for (int j = 0; j < QN; ++j) acc = dot4_lrelu(a_r[j], p_r[j], q[j], acc);
+      for (int j = 0; j < QN; ++j) {
+        const f32x4 z = p_r[j] + q[j];
+        acc = dot4_lrelu_z(a_r[j], z, acc);
+        bits |= sign4(z) << (4 * j);
+      }
+      typedef typename SignWord<QN>::type W;
+      if (active) reinterpret_cast<W*>(A.sign)[(m0 + i) * 64 + lane] = (W)bits;
+    } else {
+#pragma unroll
+      for (int j = 0; j < QN; ++j) acc = dot4_lrelu(a_r[j], p_r[j], q[j], acc);
+    }
     acc = group_sum<GL>(acc);
     const bool mine = (i & (G - 1)) == g;
     const int slot = i >> GL;
@@ -248,13 +261,13 @@ __global__ __launch_bounds__(256) void pair_loss_kernel(const float* __restrict_
 
 namespace disgat {
 
-template <int HL>
+template <int HL, bool SIGN>
 static int launch_aux3(int qn, const AuxArgs& A, int grid, hipStream_t s) {
   switch (qn) {
-    case 1: hipLaunchKernelGGL((aux_att3_kernel<HL, 1>), dim3(grid), dim3(DISGAT_BLOCK), 0, s, A); break;
-    case 2: hipLaunchKernelGGL((aux_att3_kernel<HL, 2>), dim3(grid), dim3(DISGAT_BLOCK), 0, s, A); break;
-    case 4: hipLaunchKernelGGL((aux_att3_kernel<HL, 4>), dim3(grid), dim3(DISGAT_BLOCK), 0, s, A); break;
-    case 8: hipLaunchKernelGGL((aux_att3_kernel<HL, 8>), dim3(grid), dim3(DISGAT_BLOCK), 0, s, A); break;
+    case 1: hipLaunchKernelGGL((aux_att3_kernel<HL, 1, SIGN>), dim3(grid), dim3(DISGAT_BLOCK), 0, s, A); break;
+    case 2: hipLaunchKernelGGL((aux_att3_kernel<HL, 2, SIGN>), dim3(grid), dim3(DISGAT_BLOCK), 0, s, A); break;
+    case 4: hipLaunchKernelGGL((aux_att3_kernel<HL, 4, SIGN>), dim3(grid), dim3(DISGAT_BLOCK), 0, s, A); break;
+    case 8: hipLaunchKernelGGL((aux_att3_kernel<HL, 8, SIGN>), dim3(grid), dim3(DISGAT_BLOCK), 0, s, A); break;
     default: return fail(-2, "aux_score att=3: F_out must be QN*(64/H)*4 with QN in {1,2,4,8}");
   }
   return check_launch("aux_att3_kernel");
@@ -277,7 +290,7 @@ static int launch_aux2(int xn, const AuxArgs& A, int grid, hipStream_t s) {
 extern "C" int disgat_aux_score(int att, const int64_t* pair_rows, const int64_t* pair_cols, int64_t M, int N, int H,
                                 int F_in, int F_out, int h_lo, int h_hi, const float* x, int ldx, const float* rowop,
                                 int ld_row, const float* colop, int ld_col, const float* a, float* out,
-                                disgat_stream_t stream) {
+                                void* sign_bits, disgat_stream_t stream) {
   using namespace disgat;
   DISGAT_REQUIRE(att >= 1 && att <= 3, "aux_score: att=%d not in 1..3", att);
   DISGAT_REQUIRE(M >= 0 && N > 0, "aux_score: bad sizes");
@@ -286,7 +299,8 @@ extern "C" int disgat_aux_score(int att, const int64_t* pair_rows, const int64_t
   DISGAT_REQUIRE(hl >= 1 && hl <= 4, "aux_score: H=%d must be a power of two in [2,16]", H);
   DISGAT_REQUIRE(h_lo >= 0 && h_hi <= H, "aux_score: head range [%d,%d) outside [0,%d)", h_lo, h_hi, H);
   DISGAT_REQUIRE(pair_rows && pair_cols && rowop && out, "aux_score: null pointer");
-  AuxArgs A{pair_rows, pair_cols, M, N, F_in, h_lo, h_hi, x, ldx, rowop, ld_row, colop, ld_col, a, out};
+  AuxArgs A{pair_rows, pair_cols, M, N, F_in, h_lo, h_hi, x, ldx, rowop, ld_row, colop, ld_col, a, out,
+            att == 3 ? sign_bits : nullptr};
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int64_t waves = (M + 63) / 64;
   const int64_t grid64 = (waves + DISGAT_WAVES_PER_BLOCK - 1) / DISGAT_WAVES_PER_BLOCK;
@@ -318,11 +332,19 @@ extern "C" int disgat_aux_score(int att, const int64_t* pair_rows, const int64_t
                      aligned16(rowop) && aligned16(colop) && aligned16(a),
                  "aux_score att=3: bad P/Q strides or alignment");
   const int qn = F_out / g4;
+  if (A.sign != nullptr) {
+    switch (hl) {
+      case 1: return launch_aux3<1, true>(qn, A, grid, s);
+      case 2: return launch_aux3<2, true>(qn, A, grid, s);
+      case 3: return launch_aux3<3, true>(qn, A, grid, s);
+      default: return launch_aux3<4, true>(qn, A, grid, s);
+    }
+  }
   switch (hl) {
-    case 1: return launch_aux3<1>(qn, A, grid, s);
-    case 2: return launch_aux3<2>(qn, A, grid, s);
-    case 3: return launch_aux3<3>(qn, A, grid, s);
-    default: return launch_aux3<4>(qn, A, grid, s);
+    case 1: return launch_aux3<1, false>(qn, A, grid, s);
+    case 2: return launch_aux3<2, false>(qn, A, grid, s);
+    case 3: return launch_aux3<3, false>(qn, A, grid, s);
+    default: return launch_aux3<4, false>(qn, A, grid, s);
   }
 }
 

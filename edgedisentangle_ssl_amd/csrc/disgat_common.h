@@ -102,6 +102,26 @@ __device__ __forceinline__ float dot4_lrelu(const f32x4 a, const f32x4 p, const 
   return acc;
 }
 
+// att 3 with a sign record for the backward pass: the caller forms z = P[r] + Q[c] once, scores it with
+// dot4_lrelu_z and keeps one bit per feature, (z > 0) = which slope leaky_relu took.  With those bits
+// the score's backward needs no operand gather at all (edge_bwd.hip: seg_grad_sign_kernel).
+__device__ __forceinline__ float dot4_lrelu_z(const f32x4 a, const f32x4 z, float acc) {
+  acc = fmaf(a.x, lrelu001(z.x), acc);
+  acc = fmaf(a.y, lrelu001(z.y), acc);
+  acc = fmaf(a.z, lrelu001(z.z), acc);
+  acc = fmaf(a.w, lrelu001(z.w), acc);
+  return acc;
+}
+__device__ __forceinline__ uint32_t sign4(const f32x4 z) {
+  return (z.x > 0.f ? 1u : 0u) | (z.y > 0.f ? 2u : 0u) | (z.z > 0.f ? 4u : 0u) | (z.w > 0.f ? 8u : 0u);
+}
+// Sign record of one (edge | pair): 64 lane words in lane order; bit 4*j+k of lane (h,g)'s word belongs to
+// feature h*F_out + (j*G+g)*4 + k, the float the lane owns in the P/Q/a rows.  4*QN bits per lane.
+template <int QN> struct SignWord { typedef uint32_t type; };
+template <> struct SignWord<4> { typedef uint16_t type; };
+template <> struct SignWord<2> { typedef uint8_t type; };
+template <> struct SignWord<1> { typedef uint8_t type; };
+
 __device__ __forceinline__ float dot4(const f32x4 a, const f32x4 b, float acc) {
   acc = fmaf(a.x, b.x, acc);
   acc = fmaf(a.y, b.y, acc);

@@ -251,6 +251,101 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void seg_grad_att3_kernel(const Se
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Gather-free att-3 score backward.  leaky_relu' takes two values, so with the forward's sign record
+// (one bit per (edge | pair, feature): z > 0) the gradient of e = sum_f a_f lrelu(P[key] + Q[other]) is
+//     u[key][f]  = sum_m g_m (z_mf > 0 ? 1 : 0.01) = 0.01 * sum_m g_m + 0.99 * sum_{m: bit} g_m
+//     gkey[key]  = a (.) u[key]
+//     ga         = sum_m g_m lrelu(z_m) = sum_keys keyop[key] (.) u[key]  +  the same sum of the other side's pass
+// (lrelu(z) = lrelu'(z) z and z = P + Q, so the a-gradient splits into two node-level sums).
+// Per list position this reads one 64-word sign row and H upstream gradients instead of the other side's
+// 4*H*F_out-byte operand row: 288 B instead of 8 KB at H=8, F_out=256.  Lane map as edge_fwd_kernel<3>.
+struct SignArgs {
+  const int4* items;     // {key, m_begin, m_end, slot} over a list sorted by key
+  int n_items;
+  const int32_t* perm;   // [M] or null: row of g / sign belonging to list position m
+  const float* g;        // [H][g_stride] upstream gradient of the raw scores
+  int64_t g_stride;
+  int h_lo, h_hi;
+  const void* sign;      // [M][64] SignWord<QN>
+  const float* keyop;    // P (row pass) or Q (column pass); read only when ga_part != null
+  int ld_key;
+  const float* a;
+  float* gkey;
+  int ld_gkey;
+  float* ga_part;        // [n_waves][H*FQ] or null
+};
+
+template <int HL, int QN>
+__global__ __launch_bounds__(DISGAT_BLOCK, 2) void seg_grad_sign_kernel(const SignArgs A) {
+  constexpr int GL = 6 - HL;
+  constexpr int G = 1 << GL;
+  constexpr int FQ = QN * G * 4;
+  typedef typename SignWord<QN>::type W;
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * DISGAT_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+  const int n_waves = gridDim.x * DISGAT_WAVES_PER_BLOCK;
+  const int myh = lane >> GL;
+  const bool active = (myh >= A.h_lo) && (myh < A.h_hi);
+  const int qoff = myh * FQ + (lane & (G - 1)) * 4;
+  const W* sg = reinterpret_cast<const W*>(A.sign) + lane;
+  const float* gh = A.g + (int64_t)myh * A.g_stride;
+  const bool want_ga = A.ga_part != nullptr;
+
+  f32x4 ga[QN];
+#pragma unroll
+  for (int j = 0; j < QN; ++j) ga[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int item = wave; item < A.n_items; item += n_waves) {   // persistent: ga stays in registers
+    const int4 it = A.items[item];
+    const int key = rfl(it.x), mb = rfl(it.y), me = rfl(it.z), slot = rfl(it.w);
+    f32x4 up[QN];
+#pragma unroll
+    for (int j = 0; j < QN; ++j) up[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float gall = 0.f;
+    for (int mbase = mb; mbase < me; mbase += 64) {
+      const int cnt = min(64, me - mbase);
+      const int pv = (lane < cnt) ? (A.perm ? A.perm[mbase + lane] : mbase + lane) : 0;
+      for (int i = 0; i < cnt; i += 4) {          // 4 positions in flight; lanes >= cnt hold position 0 (valid memory)
+        uint32_t w[4];
+        float gv[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int64_t pos = __builtin_amdgcn_readlane(pv, i + t);
+          w[t] = sg[pos * 64];
+          gv[t] = (active && i + t < cnt) ? gh[pos] : 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          __builtin_amdgcn_sched_barrier(0);      // one position at a time: keeps the 32 bit->float temporaries from piling up
+          gall += gv[t];
+#pragma unroll
+          for (int j = 0; j < QN; ++j) {
+            up[j].x = fmaf(gv[t], (float)((w[t] >> (4 * j + 0)) & 1u), up[j].x);
+            up[j].y = fmaf(gv[t], (float)((w[t] >> (4 * j + 1)) & 1u), up[j].y);
+            up[j].z = fmaf(gv[t], (float)((w[t] >> (4 * j + 2)) & 1u), up[j].z);
+            up[j].w = fmaf(gv[t], (float)((w[t] >> (4 * j + 3)) & 1u), up[j].w);
+          }
+        }
+      }
+    }
+    float* op = A.gkey + (size_t)key * A.ld_gkey + qoff;
+    const float base = 0.01f * gall;
+    const float* pp = A.keyop + (size_t)key * A.ld_key + qoff;
+#pragma unroll
+    for (int j = 0; j < QN; ++j) {           // a (8 KB, cache-resident) and the key's operand row are read here, once per item
+      const f32x4 u = 0.99f * up[j] + base;
+      if (want_ga) ga[j] += ld4(pp + j * G * 4) * u;
+      out4(op + j * G * 4, ld4(A.a + qoff + j * G * 4) * u, slot >= 0, false);
+    }
+  }
+  if (want_ga) {
+    float* gp = A.ga_part + (size_t)wave * (FQ << HL) + qoff;
+#pragma unroll
+    for (int j = 0; j < QN; ++j) st4(gp + j * G * 4, ga[j]);
+  }
+}
+
 // gkey[key][h][:] = sum_m coef[h][pos(m)] * X[other_m][:]
 template <int HL, int XN>
 __global__ __launch_bounds__(DISGAT_BLOCK, 2) void seg_grad_hx_row_kernel(const SegArgs A) {
@@ -443,6 +538,47 @@ extern "C" int disgat_seg_grad_att3(const int32_t* items, int n_items, const int
 #undef DISGAT_SGQ
 #undef DISGAT_SG
   return check_launch("seg_grad_att3_kernel");
+}
+
+extern "C" int disgat_seg_grad_sign(const int32_t* items, int n_items, const int32_t* perm, const float* g,
+                                    int64_t g_stride, int h_lo, int h_hi, int H, int F_out, const void* sign_bits,
+                                    const float* keyop, int ld_key, const float* a, float* gkey, int ld_gkey,
+                                    float* ga_part, int n_waves, disgat_stream_t stream) {
+  using namespace disgat;
+  if (n_items == 0) return 0;
+  const int hl = ilog2_exact(H);
+  DISGAT_REQUIRE(hl >= 1 && hl <= 4, "seg_grad_sign: H=%d must be a power of two in [2,16]", H);
+  DISGAT_REQUIRE(h_lo >= 0 && h_hi <= H && h_lo < h_hi, "seg_grad_sign: bad head range [%d,%d)", h_lo, h_hi);
+  DISGAT_REQUIRE(items && g && sign_bits && a && gkey && n_items > 0, "seg_grad_sign: null pointer");
+  DISGAT_REQUIRE(ga_part == nullptr || keyop != nullptr, "seg_grad_sign: ga_part needs keyop");
+  const int g4 = (64 >> hl) * 4;
+  DISGAT_REQUIRE(F_out > 0 && F_out % g4 == 0, "seg_grad_sign: bad F_out=%d", F_out);
+  DISGAT_REQUIRE(ld_gkey % 4 == 0 && ld_key % 4 == 0 && aligned16(a) && aligned16(gkey) && (keyop == nullptr || aligned16(keyop)),
+                 "seg_grad_sign: strides must be multiples of 4 floats and bases 16-byte aligned");
+  DISGAT_REQUIRE(n_waves > 0 && n_waves % DISGAT_WAVES_PER_BLOCK == 0, "seg_grad_sign: n_waves must be a positive multiple of %d", DISGAT_WAVES_PER_BLOCK);
+  const int qn = F_out / g4;
+  SignArgs A{reinterpret_cast<const int4*>(items), n_items, perm, g, g_stride, h_lo, h_hi, sign_bits, keyop, ld_key, a,
+             gkey, ld_gkey, ga_part};
+  const dim3 grid(n_waves / DISGAT_WAVES_PER_BLOCK), block(DISGAT_BLOCK);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+#define DISGAT_SS(HL_, QN_) hipLaunchKernelGGL((seg_grad_sign_kernel<HL_, QN_>), grid, block, 0, s, A)
+#define DISGAT_SSQ(HL_)                                                                        \
+  switch (qn) {                                                                                \
+    case 1: DISGAT_SS(HL_, 1); break;                                                          \
+    case 2: DISGAT_SS(HL_, 2); break;                                                          \
+    case 4: DISGAT_SS(HL_, 4); break;                                                          \
+    case 8: DISGAT_SS(HL_, 8); break;                                                          \
+    default: return fail(-2, "seg_grad_sign: F_out must be QN*(64/H)*4 with QN in {1,2,4,8}"); \
+  }
+  switch (hl) {
+    case 1: DISGAT_SSQ(1); break;
+    case 2: DISGAT_SSQ(2); break;
+    case 3: DISGAT_SSQ(3); break;
+    default: DISGAT_SSQ(4); break;
+  }
+#undef DISGAT_SSQ
+#undef DISGAT_SS
+  return check_launch("seg_grad_sign_kernel");
 }
 
 template <bool COL>

@@ -44,6 +44,7 @@ struct EdgeFwdArgs {
   float* part_den;
   int sage_div;
   DropCfg drop;
+  void* sign;           // att 3, optional: [E][64] sign words (disgat_common.h SignWord) for the backward pass
 };
 
 template <int ATT, int HL, int QN, int XN>
@@ -53,7 +54,7 @@ struct ColBuf {
   float s2;
 };
 
-template <int ATT, int HL, int QN, int XN>
+template <int ATT, int HL, int QN, int XN, bool SIGN>
 __global__ __launch_bounds__(DISGAT_BLOCK, 2) void edge_fwd_kernel(const EdgeFwdArgs A) {
   constexpr int H = 1 << HL;
   constexpr int GL = 6 - HL;
@@ -127,7 +128,19 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void edge_fwd_kernel(const EdgeFwd
   float keep[H];
   auto compute = [&](const Buf& b, int64_t k, int i) {
     float e;
-    if constexpr (ATT == 3) {
+    if constexpr (ATT == 3 && SIGN) {
+      float acc = 0.f;
+      uint32_t bits = 0u;
+#pragma unroll
+      for (int j = 0; j < QN; ++j) {
+        const f32x4 z = p_r[j] + b.q[j];
+        acc = dot4_lrelu_z(a_r[j], z, acc);
+        bits |= sign4(z) << (4 * j);
+      }
+      typedef typename SignWord<QN>::type W;
+      reinterpret_cast<W*>(A.sign)[k * 64 + lane] = (W)bits;     // one 64-word row per edge, coalesced
+      e = group_sum<GL>(acc);
+    } else if constexpr (ATT == 3) {
       float acc = 0.f;
 #pragma unroll
       for (int j = 0; j < QN; ++j) acc = dot4_lrelu(a_r[j], p_r[j], b.q[j], acc);
@@ -255,7 +268,13 @@ namespace disgat {
 template <int ATT, int HL, int QN, int XN>
 static int launch_edge(const EdgeFwdArgs& args, hipStream_t stream) {
   const int grid = (args.n_items + DISGAT_WAVES_PER_BLOCK - 1) / DISGAT_WAVES_PER_BLOCK;
-  hipLaunchKernelGGL((edge_fwd_kernel<ATT, HL, QN, XN>), dim3(grid), dim3(DISGAT_BLOCK), 0, stream, args);
+  if constexpr (ATT == 3) {
+    if (args.sign != nullptr) {
+      hipLaunchKernelGGL((edge_fwd_kernel<ATT, HL, QN, XN, true>), dim3(grid), dim3(DISGAT_BLOCK), 0, stream, args);
+      return check_launch("edge_fwd_kernel");
+    }
+  }
+  hipLaunchKernelGGL((edge_fwd_kernel<ATT, HL, QN, XN, false>), dim3(grid), dim3(DISGAT_BLOCK), 0, stream, args);
   return check_launch("edge_fwd_kernel");
 }
 
@@ -300,7 +319,7 @@ extern "C" int disgat_edge_fwd(int att, const int32_t* items, int n_items, const
                                int F_in, int F_out, const float* x, int ldx, const float* rowop, int ld_row,
                                const float* colop, int ld_col, const float* a, float* Z, float* edge_e, float* den,
                                float* part_z, float* part_den, int sage_div, float drop_p, uint64_t drop_seed,
-                               disgat_stream_t stream) {
+                               void* sign_bits, disgat_stream_t stream) {
   using namespace disgat;
   DISGAT_REQUIRE(att >= 1 && att <= 3, "edge_fwd: att=%d not in 1..3", att);
   DISGAT_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "edge_fwd: dropout p=%f outside [0,1)", (double)drop_p);
@@ -327,7 +346,8 @@ extern "C" int disgat_edge_fwd(int att, const int32_t* items, int n_items, const
   }
   EdgeFwdArgs args{reinterpret_cast<const int4*>(items), n_items, col, E, N, F_in, x, ldx, rowop, ld_row, colop, ld_col,
                    a, Z, edge_e, den, part_z, part_den, sage_div,
-                   DropCfg{drop_seed, (uint32_t)((double)drop_p * 4294967296.0), 1.0f / (1.0f - drop_p)}};
+                   DropCfg{drop_seed, (uint32_t)((double)drop_p * 4294967296.0), 1.0f / (1.0f - drop_p)},
+                   att == 3 ? sign_bits : nullptr};
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   switch (att) {
     case 1: return launch_edge_h<1>(hl, qn, xn, args, s);

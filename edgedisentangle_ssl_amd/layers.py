@@ -222,19 +222,20 @@ def disga_heads(layers, x, adj, aux_indices=None, head_ranges=None, aux_only=Fal
         d = (drop[0], drop[1] + 0x9E3779B1 * gi) if drop[0] > 0 else drop      # independent masks per group
         return r, c, av, d
 
+    rec = ops.wants_sign(att, rowop, colop, a_vec)     # att 3: record lrelu signs for a gather-free backward
     heads = e_list = None
     if not aux_only:
         z_groups, e_groups = [], []
         for gi in range(n_groups):
             r, c, av, d = group_ops(gi)
             if f_in_p <= tile:
-                cfg = (graph, att, Hk, f_in_p, fp, gnn == "SAGE", d)
+                cfg = (graph, att, Hk, f_in_p, fp, gnn == "SAGE", d, rec)
                 z, edge_e, _den = ops.EdgePass.apply(xg, r, c, av, cfg)
             else:
                 zs, edge_e = [], None
                 for c0 in range(0, f_in_p, tile):
                     c1 = min(f_in_p, c0 + tile)
-                    cfg = (graph, att, Hk, c1 - c0, fp, gnn == "SAGE", d)
+                    cfg = (graph, att, Hk, c1 - c0, fp, gnn == "SAGE", d, rec)
                     zc, ec, _den = ops.EdgePass.apply(xg[:, c0:c1], r, c, av, cfg)
                     zs.append(zc)
                     edge_e = ec if edge_e is None else edge_e
@@ -280,7 +281,7 @@ def disga_heads(layers, x, adj, aux_indices=None, head_ranges=None, aux_only=Fal
                 if g_lo >= g_hi:
                     continue
                 r, c, av, _d = group_ops(gi)
-                acfg = (att, Hk, f_in_p, fp, graph.n, g_lo - gi * Hk, g_hi - gi * Hk)
+                acfg = (att, Hk, f_in_p, fp, graph.n, g_lo - gi * Hk, g_hi - gi * Hk, rec)
                 out = ops.AuxPass.apply(xg if att == 2 else None, r, c, av, pairs, acfg)
                 for h in range(g_lo, g_hi):
                     per_head[h] = out[h - gi * Hk].unsqueeze(1)

@@ -45,6 +45,25 @@ def aux_algorithmic_bytes(att, n, m, nheads, F_in, F_out):
     return m * (8 + 4 * s) + n * 4 * s
 
 
+# att 3 backward from the forward's sign record (csrc/edge_bwd.hip: seg_grad_sign_kernel) instead of a second
+# gather of the operand rows: ~28x fewer bytes per edge in the score backward for 256 B per (edge | pair) of
+# extra state between forward and backward.  False selects the gather-only kernels (no extra state).
+SIGN_BACKWARD = True
+
+
+def sign_record(att, H, F_out, count, dev):
+    """uint8 [count, 64*w] buffer for the att-3 sign words (layout: include/disgat_hip.h `sign_bits`)."""
+    qn = F_out // ((64 // H) * 4)
+    return torch.empty((count, 64 * {8: 4, 4: 2, 2: 1, 1: 1}[qn]), dtype=torch.uint8, device=dev)
+
+
+def wants_sign(att, *operands):
+    """True when a differentiable att-3 pass should record signs (decided outside autograd.Function.forward,
+    where grad mode is always off)."""
+    return (SIGN_BACKWARD and att == 3 and torch.is_grad_enabled()
+            and any(t is not None and t.requires_grad for t in operands))
+
+
 def _ptr(t):
     return 0 if t is None else t.data_ptr()
 
@@ -66,12 +85,13 @@ def _row_major(t, name):
     return t
 
 
-def edge_forward(graph: CSRGraph, att, H, F_in, F_out, x, rowop, colop, a, sage_div, drop=(0.0, 0), need_den=True):
+def edge_forward(graph: CSRGraph, att, H, F_in, F_out, x, rowop, colop, a, sage_div, drop=(0.0, 0), need_den=True,
+                 sign=None):
     """Launch disgat_edge_fwd (+ disgat_edge_combine for split rows).
 
     x [N, >=F_in] (row stride % 4 == 0), rowop/colop 2-D views with unit inner
-    stride, a [H*F_out] or None; drop = (p, seed) of the attention dropout.  Returns Z [N,H,F_in],
-    edge_e [H,E], den [N,2,H].
+    stride, a [H*F_out] or None; drop = (p, seed) of the attention dropout; sign: optional
+    sign_record(...) buffer the att-3 kernel fills.  Returns Z [N,H,F_in], edge_e [H,E], den [N,2,H].
     """
     for t, nm in ((x, "x"), (rowop, "rowop")) + (((colop, "colop"),) if colop is not None else ()):
         _check(t, nm)
@@ -91,14 +111,14 @@ def edge_forward(graph: CSRGraph, att, H, F_in, F_out, x, rowop, colop, a, sage_
             att, _ptr(wi.items), wi.n_items, _ptr(graph.col), e, n, H, F_in, F_out,
               _ptr(x), x.stride(0), _ptr(rowop), rowop.stride(0), _ptr(colop), 0 if colop is None else colop.stride(0),
               _ptr(a), _ptr(z), _ptr(edge_e), _ptr(den), _ptr(part_z), _ptr(part_den), int(bool(sage_div)),
-              float(drop[0]), int(drop[1]), st)
+              float(drop[0]), int(drop[1]), _ptr(sign), st)
     if wi.n_split:
         _lib.call("disgat_edge_combine", _ptr(wi.split_rows), _ptr(wi.split_ptr), wi.n_split, H, F_in,
                   _ptr(part_z), _ptr(part_den), _ptr(z), _ptr(den), int(bool(sage_div)), st)
     return z, edge_e, den
 
 
-def aux_forward(att, H, F_in, F_out, pairs, n, x, rowop, colop, a, h_lo=0, h_hi=None):
+def aux_forward(att, H, F_in, F_out, pairs, n, x, rowop, colop, a, h_lo=0, h_hi=None, sign=None):
     """Launch disgat_aux_score.  pairs: int64 [2,M] device tensor.  Returns [H,M]
     (rows outside [h_lo,h_hi) are left uninitialised and must not be read)."""
     if pairs.dtype != torch.int64 or not pairs.is_cuda:
@@ -110,7 +130,7 @@ def aux_forward(att, H, F_in, F_out, pairs, n, x, rowop, colop, a, h_lo=0, h_hi=
     _launch("disgat_aux_score", f"aux_score_att{att}", aux_algorithmic_bytes(att, n, m, h_hi - h_lo, F_in, F_out),
             att, pairs[0].data_ptr(), pairs[1].data_ptr(), m, n, H, F_in, F_out, h_lo, h_hi,
               _ptr(x), 0 if x is None else x.stride(0), _ptr(rowop), rowop.stride(0),
-              _ptr(colop), 0 if colop is None else colop.stride(0), _ptr(a), _ptr(out), _stream())
+              _ptr(colop), 0 if colop is None else colop.stride(0), _ptr(a), _ptr(out), _ptr(sign), _stream())
     return out
 
 
@@ -130,9 +150,10 @@ class EdgePass(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, rowop, colop, a, cfg):
-        graph, att, H, F_in, F_out, sage, drop = cfg
-        z, edge_e, den = edge_forward(graph, att, H, F_in, F_out, x, rowop, colop, a, sage, drop)
-        ctx.cfg = cfg
+        graph, att, H, F_in, F_out, sage, drop = cfg[:7]
+        ctx.sign = sign_record(att, H, F_out, graph.nnz, x.device) if (len(cfg) > 7 and cfg[7] and graph.nnz) else None
+        z, edge_e, den = edge_forward(graph, att, H, F_in, F_out, x, rowop, colop, a, sage, drop, sign=ctx.sign)
+        ctx.cfg = cfg[:7]
         ctx.save_for_backward(x, rowop, colop, a, z, edge_e, den)
         ctx.mark_non_differentiable(den)
         return z, edge_e, den
@@ -146,9 +167,11 @@ class EdgePass(torch.autograd.Function):
 class AuxPass(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, rowop, colop, a, pairs, cfg):
-        att, H, F_in, F_out, n, h_lo, h_hi = cfg
-        out = aux_forward(att, H, F_in, F_out, pairs, n, x, rowop, colop, a, h_lo, h_hi)
-        ctx.cfg = cfg
+        att, H, F_in, F_out, n, h_lo, h_hi = cfg[:7]
+        m = int(pairs.shape[1])
+        ctx.sign = sign_record(att, H, F_out, m, pairs.device) if (len(cfg) > 7 and cfg[7] and m) else None
+        out = aux_forward(att, H, F_in, F_out, pairs, n, x, rowop, colop, a, h_lo, h_hi, sign=ctx.sign)
+        ctx.cfg = cfg[:7]
         ctx.save_for_backward(x, rowop, colop, a, pairs)
         return out
 

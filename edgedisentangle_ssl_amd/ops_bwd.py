@@ -22,6 +22,19 @@ def _seg_att3(wi, other, perm, g, lo, hi, H, f_out, keyop, otherop, a, n_keys, w
     return gkey, (ga_part.sum(0) if want_ga else None)
 
 
+def _seg_sign(wi, perm, g, lo, hi, H, f_out, sign, keyop, a, n_keys, want_ga):
+    """Score backward of one side (rows: keyop = P, columns: keyop = Q) from the forward's sign record.
+    Returns (gkey [n_keys, H*f_out], this side's share of grad a or None)."""
+    dev = g.device
+    gkey = _buf((n_keys, H * f_out), dev, wi.n_split > 0)
+    n_waves = min(_MAX_WAVES, (wi.n_items + 3) // 4 * 4)
+    ga_part = torch.empty((n_waves, H * f_out), dtype=torch.float32, device=dev) if want_ga else None
+    _lib.call("disgat_seg_grad_sign", wi.items.data_ptr(), wi.n_items, ops._ptr(perm), g.data_ptr(), g.stride(0), lo, hi,
+              H, f_out, sign.data_ptr(), keyop.data_ptr(), keyop.stride(0), a.data_ptr(), gkey.data_ptr(), gkey.stride(0),
+              ops._ptr(ga_part), n_waves, ops._stream())
+    return gkey, (ga_part.sum(0) if want_ga else None)
+
+
 def _seg_hx(col_mode, wi, other, perm, coef, lo, hi, H, f, otherop, gkey, accumulate):
     _lib.call("disgat_seg_grad_hx", int(col_mode), wi.items.data_ptr(), wi.n_items, other.data_ptr(), ops._ptr(perm),
               coef.data_ptr(), coef.stride(0), lo, hi, H, f, otherop.data_ptr(), otherop.stride(0), gkey.data_ptr(),
@@ -47,7 +60,8 @@ def edge_backward(ctx, gz, ge):
               beta.data_ptr(), int(bool(sage)), float(drop[0]), int(drop[1]), ops._stream())
     g_x = g_row = g_col = g_a = None
     t = twi = None
-    if need_x or (att == 3 and need_col):
+    sign = getattr(ctx, "sign", None)
+    if need_x or (att == 3 and (need_col or (need_a and sign is not None))):
         t = graph.transpose()
         twi = t.work_items(chunk)
     if att == 1:
@@ -60,6 +74,12 @@ def edge_backward(ctx, gz, ge):
         if need_row:                                    # gP[r,h,:] = sum_k ge_k x[col_k]
             g_row = _buf((n, H * f_in), dev, wi.n_split > 0)
             _seg_hx(0, wi, graph.col, None, ge_tot, 0, H, H, f_in, x, g_row, False)
+    elif sign is not None:                              # gather-free: both sides read the sign record
+        if need_row or need_a:
+            g_row, g_a = _seg_sign(wi, None, ge_tot, 0, H, H, f_out, sign, rowop, a, n, need_a)
+        if need_col or need_a:
+            g_col, ga_c = _seg_sign(twi, t.eid, ge_tot, 0, H, H, f_out, sign, colop, a, colop.shape[0], need_a)
+            g_a = g_a + ga_c if need_a else None
     else:
         if need_row or need_a:
             g_row, g_a = _seg_att3(wi, graph.col, None, ge_tot, 0, H, H, f_out, rowop, colop, a, n, need_a)
@@ -109,6 +129,16 @@ def aux_backward(ctx, gout):
     chunk = ops.CHUNK[att]
     n_rows = rowop.shape[0]
     n_cols = colop.shape[0] if att == 3 else x.shape[0]
+    sign = getattr(ctx, "sign", None)
+    if att == 3 and sign is not None:                   # gather-free: only the keys and the sign record are read
+        if need_row or need_a:
+            wi, _perm, perm32 = _segments(rows, n_rows, chunk)
+            g_row, g_a = _seg_sign(wi, perm32, gout, lo, hi, H, f_out, sign, rowop, a, n_rows, need_a)
+        if need_col or need_a:
+            wi, _perm, perm32 = _segments(cols, n_cols, chunk)
+            g_col, ga_c = _seg_sign(wi, perm32, gout, lo, hi, H, f_out, sign, colop, a, n_cols, need_a)
+            g_a = g_a + ga_c if need_a else None
+        return g_x, g_row, g_col, g_a, None, None
     if need_row or need_a:
         wi, perm, perm32 = _segments(rows, n_rows, chunk)
         other = (cols if perm is None else cols[perm]).to(torch.int32)

@@ -39,6 +39,12 @@
  *   part_z / part_den   [n_slots][H][F_in] / [n_slots][2][H] partial records of split rows
  *   drop_p, drop_seed   attention dropout (layers.py:394): edge k, head h is kept iff the top 32 bits
  *                       of splitmix64(seed + (k*H+h)*0x9E3779B97F4A7C15) >= p*2^32; p = 0 disables it
+ *   sign_bits           att 3 only, optional (NULL = not recorded): [E | M][64] words of 4*QN bits rounded up to
+ *                       1, 2 or 4 bytes (QN = F_out / ((64/H)*4): QN 8 -> uint32, 4 -> uint16, 2 and 1 -> uint8).
+ *                       Word l of a row belongs to lane l = (head h = l / G, g = l % G), G = 64/H; its bit
+ *                       4*j+k is (P[row] + Q[col] > 0) at feature h*F_out + (j*G+g)*4 + k: which slope
+ *                       leaky_relu took.  disgat_seg_grad_sign computes the score's backward from it
+ *                       without gathering any operand row.
  *   H must be a power of two (the host pads missing heads with zero weights).
  *
  * att (the reference's --att / att_type):
@@ -72,7 +78,7 @@ int disgat_edge_fwd(int att, const int32_t* items, int n_items, const int32_t* c
                     float* Z, float* edge_e, float* den,
                     float* part_z, float* part_den,
                     int sage_div, float drop_p, uint64_t drop_seed,
-                    disgat_stream_t stream);
+                    void* sign_bits, disgat_stream_t stream);
 
 /* Sums the partial records of split rows (in chunk order: deterministic) and normalises. */
 int disgat_edge_combine(const int32_t* split_rows, const int32_t* split_ptr, int n_split,
@@ -86,7 +92,7 @@ int disgat_aux_score(int att, const int64_t* pair_rows, const int64_t* pair_cols
                      const float* rowop, int ld_row,
                      const float* colop, int ld_col,
                      const float* a,
-                     float* out, disgat_stream_t stream);
+                     float* out, void* sign_bits, disgat_stream_t stream);
 
 /* Weighted squared-error partial sums of pred = sigmoid(sum_{h in [h_lo,h_hi)} aux[h][m])
  * against 0/1 labels: acc[0] += sum over positives, acc[1] += sum over zeros, acc[2] += #positives.
@@ -114,6 +120,17 @@ int disgat_seg_grad_att3(const int32_t* items, int n_items, const int32_t* other
                          const float* g, int64_t g_stride, int h_lo, int h_hi, int H, int F_out,
                          const float* keyop, int ld_key, const float* otherop, int ld_other, const float* a,
                          float* gkey, int ld_gkey, float* ga_part, int n_waves, disgat_stream_t stream);
+
+/* The same gradient from the forward's sign record instead of a second operand gather (layout: sign_bits
+ * above; row perm[m] of g and sign_bits belongs to list position m, NULL = identity):
+ *   u[key] = sum_m g_m * (bit ? 1 : 0.01),  gkey[key] = a (.) u[key]  (atomic add into host-zeroed rows when
+ *   slot >= 0),  ga_part[wave] = per-wave partial of sum_key keyop[key] (.) u[key]  (NULL: not wanted).
+ * The a-gradient of a list is the sum of the row-side pass (keyop = P) and the column-side pass (keyop = Q),
+ * because lrelu(z) = lrelu'(z) * (P + Q).  Reads 64 words + H floats per list position. */
+int disgat_seg_grad_sign(const int32_t* items, int n_items, const int32_t* perm, const float* g,
+                         int64_t g_stride, int h_lo, int h_hi, int H, int F_out, const void* sign_bits,
+                         const float* keyop, int ld_key, const float* a, float* gkey, int ld_gkey,
+                         float* ga_part, int n_waves, disgat_stream_t stream);
 
 /* col_mode = 0: gkey[key][h][:] = sum_m coef[h][perm(m)] * otherop[other_m][:]          (F floats per row)
  * col_mode = 1: gkey[key][:] (+)= sum_m sum_h coef[h][perm(m)] * otherop[other_m][h][:]  (otherop rows H*F) */

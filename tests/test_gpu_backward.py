@@ -44,11 +44,15 @@ def _check(enc, g, prefix, tol=GTOL):
         close(got, g[f"{prefix}.{k}"], tol=tol, what=f"{prefix}.{k}")
 
 
-@pytest.mark.parametrize("chunk", [None, 8])
+@pytest.mark.parametrize("chunk,sign", [(None, True), (8, True), (None, False), (8, False)])
 @pytest.mark.parametrize("gnn", GNNS)
 @pytest.mark.parametrize("att", ATTS)
-def test_tiny_loss_gradients(golden_dir, dev, gnn, att, chunk, monkeypatch):
+def test_tiny_loss_gradients(golden_dir, dev, gnn, att, chunk, sign, monkeypatch):
+    """sign: att-3 score backward from the forward's sign record (default) or by re-gathering the operands."""
     from edgedisentangle_ssl_amd import ops
+    if att != 3 and not sign:
+        pytest.skip("the sign record exists for att 3 only")
+    monkeypatch.setattr(ops, "SIGN_BACKWARD", sign)
     if chunk is not None:
         monkeypatch.setattr(ops, "CHUNK", {1: chunk, 2: chunk, 3: chunk})
     g = np.load(os.path.join(golden_dir, f"tiny_{gnn}_att{att}.npz"))
@@ -144,3 +148,31 @@ def test_backward_with_empty_graph_and_empty_pair_list(dev):
     for lay in layers:
         assert all(p.grad is None or torch.isfinite(p.grad).all() for p in lay.parameters())
         assert lay.W.grad is not None and float(lay.W.grad.abs().sum()) > 0       # through the one scored pair list
+
+
+@pytest.mark.parametrize("sign", [True, False])
+def test_att3_gradient_at_the_leaky_relu_kink(dev, sign, monkeypatch):
+    """All-zero feature rows make z = P[r] + Q[c] exactly 0 for (zero, zero) pairs; ATen's leaky_relu backward
+    takes the 0.01 slope there (x > 0 is false).  Both backward variants must agree with the oracle's autograd."""
+    from edgedisentangle_ssl_amd import ops
+    from edgedisentangle_ssl_amd.layers import DisGALayer
+    from oracle import disgat_oracle as orc
+    monkeypatch.setattr(ops, "SIGN_BACKWARD", sign)
+    x, adj, n, aux = tiny_inputs(dev)
+    x = x.clone()
+    x[::3] = 0.0                                           # every third node has no features
+    lay = DisGALayer(x.shape[1], 16, dropout=0.0, alpha=0.1, concat=True, att_type=3, gnn_type="AT")
+    ic.load_params(lay, 77)
+    lay_d = DisGALayer(x.shape[1], 16, dropout=0.0, alpha=0.1, concat=True, att_type=3, gnn_type="AT").to(dev)
+    lay_d.load_state_dict(lay.state_dict())
+    h, e, au = lay_d(x, adj, [t.to(dev) for t in aux])
+    w = torch.from_numpy(np.random.Generator(np.random.PCG64(9)).standard_normal(tuple(h.shape)).astype(np.float32)).to(dev)
+    ((h * w).sum() + (e * e).sum() + sum((t * t).sum() for t in au)).backward()
+
+    xc = x.cpu().double()
+    p = {k: v.detach().double().requires_grad_(True) for k, v in lay.state_dict().items()}
+    ci = orc.coalesced_indices(adj.cpu())
+    h_o, e_o, au_o = orc.disga_layer(xc, ci, p, 3, "AT", [t.cpu() for t in aux])
+    ((h_o * w.cpu().double()).sum() + (e_o * e_o).sum() + sum((t * t).sum() for t in au_o)).backward()
+    for k, v in lay_d.named_parameters():
+        close(v.grad, p[k].grad.float().numpy(), tol=GTOL, what=f"kink grad {k} (sign={sign})")
