@@ -27,7 +27,7 @@ struct AuxArgs {
   int ld_col;
   const float* a;
   float* out;
-  void* sign;   // att 3, optional: [M][64] sign words for the backward pass (disgat_common.h SignWord)
+  uint32_t* sign;   // att 3, optional: [M][64] sign words for the backward pass (disgat_common.h)
 };
 
 // att 3: lane = (head, g) exactly as in edge_fwd_kernel<3,...>.
@@ -81,15 +81,12 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void aux_att3_kernel(const AuxArgs
     }
     float acc = 0.f;
     if constexpr (SIGN) {
-      uint32_t bits = 0u;
+      SignAcc sg;
 #pragma unroll
-      for (int j = 0; j < QN; ++j) {
-        const f32x4 z = p_r[j] + q[j];
-        acc = dot4_lrelu_z(a_r[j], z, acc);
-        bits |= sign4(z) << (4 * j);
-      }
-      typedef typename SignWord<QN>::type W;
-      if (active) reinterpret_cast<W*>(A.sign)[(m0 + i) * 64 + lane] = (W)bits;
+      for (int j = 0; j < QN; ++j) acc = dot4_lrelu_sign(a_r[j], p_r[j], q[j], acc, sg);
+      // every lane stores (whole 64-word rows; the words of unscored heads are never read): a store under
+      // `active` also splits the block and costs a second v_max per feature (z no longer known canonical)
+      A.sign[(m0 + i) * 64 + lane] = sg.word();
     } else {
 #pragma unroll
       for (int j = 0; j < QN; ++j) acc = dot4_lrelu(a_r[j], p_r[j], q[j], acc);
@@ -290,7 +287,7 @@ static int launch_aux2(int xn, const AuxArgs& A, int grid, hipStream_t s) {
 extern "C" int disgat_aux_score(int att, const int64_t* pair_rows, const int64_t* pair_cols, int64_t M, int N, int H,
                                 int F_in, int F_out, int h_lo, int h_hi, const float* x, int ldx, const float* rowop,
                                 int ld_row, const float* colop, int ld_col, const float* a, float* out,
-                                void* sign_bits, disgat_stream_t stream) {
+                                uint32_t* sign_bits, disgat_stream_t stream) {
   using namespace disgat;
   DISGAT_REQUIRE(att >= 1 && att <= 3, "aux_score: att=%d not in 1..3", att);
   DISGAT_REQUIRE(M >= 0 && N > 0, "aux_score: bad sizes");

@@ -102,25 +102,43 @@ __device__ __forceinline__ float dot4_lrelu(const f32x4 a, const f32x4 p, const 
   return acc;
 }
 
-// att 3 with a sign record for the backward pass: the caller forms z = P[r] + Q[c] once, scores it with
-// dot4_lrelu_z and keeps one bit per feature, (z > 0) = which slope leaky_relu took.  With those bits
-// the score's backward needs no operand gather at all (edge_bwd.hip: seg_grad_sign_kernel).
-__device__ __forceinline__ float dot4_lrelu_z(const f32x4 a, const f32x4 z, float acc) {
-  acc = fmaf(a.x, lrelu001(z.x), acc);
-  acc = fmaf(a.y, lrelu001(z.y), acc);
-  acc = fmaf(a.z, lrelu001(z.z), acc);
-  acc = fmaf(a.w, lrelu001(z.w), acc);
+// att 3 with a sign record for the backward pass: one bit per feature, (z > 0) = which slope leaky_relu
+// took at z = P[r] + Q[c].  With those bits the score's backward needs no operand gather at all
+// (edge_bwd.hip: seg_grad_sign_kernel).
+//
+// Record of one (edge | pair): 64 uint32 words in lane order.  Lane (h,g) owns features h*F_out + (j*G+g)*4 + k
+// (j < QN float4 groups, k < 4 components); its word keeps component k in byte k and group j at bit QN-1-j of
+// that byte: bit 8*k + QN-1-j.  Byte-per-component lets the backward turn 4 bits into 4 floats with one shift,
+// one and (0x01010101) and four v_cvt_f32_ubyteN.
+//
+// sign_push: shift left and append (z > 0).  z > 0 as an integer test on the float's bits s: s > 0 as int32
+// (negative floats and -0.0 carry the sign bit, +0.0 is 0), i.e. the sign bit of the saturating 0 - s
+// (saturation keeps -0.0 = INT_MIN on the "not positive" side); v_alignbit appends it: 2 VALU ops per feature.
+__device__ __forceinline__ uint32_t sign_push(uint32_t bits, float z) {
+  const int t = __builtin_elementwise_sub_sat(0, __float_as_int(z));
+  return __builtin_amdgcn_alignbit(bits, (uint32_t)t, 31);
+}
+struct SignAcc {
+  uint32_t b0 = 0u, b1 = 0u, b2 = 0u, b3 = 0u;
+  __device__ __forceinline__ uint32_t word() const { return b0 | (b1 << 8) | (b2 << 16) | (b3 << 24); }
+};
+// dot4_lrelu that also pushes the 4 signs (kept scalar per feature: routed through a float4 temporary the
+// compiler forgets that z is the canonical result of an add and spends a second v_max per feature on fmaxf)
+__device__ __forceinline__ float dot4_lrelu_sign(const f32x4 a, const f32x4 p, const f32x4 q, float acc, SignAcc& s) {
+  float z;
+  z = p.x + q.x; acc = fmaf(a.x, lrelu001(z), acc); s.b0 = sign_push(s.b0, z);
+  z = p.y + q.y; acc = fmaf(a.y, lrelu001(z), acc); s.b1 = sign_push(s.b1, z);
+  z = p.z + q.z; acc = fmaf(a.z, lrelu001(z), acc); s.b2 = sign_push(s.b2, z);
+  z = p.w + q.w; acc = fmaf(a.w, lrelu001(z), acc); s.b3 = sign_push(s.b3, z);
   return acc;
 }
-__device__ __forceinline__ uint32_t sign4(const f32x4 z) {
-  return (z.x > 0.f ? 1u : 0u) | (z.y > 0.f ? 2u : 0u) | (z.z > 0.f ? 4u : 0u) | (z.w > 0.f ? 8u : 0u);
+// the 4 components of float4 group j of a sign word as 0.0 / 1.0
+template <int QN>
+__device__ __forceinline__ f32x4 sign_floats(uint32_t w, int j) {
+  uint32_t t = (w >> (QN - 1 - j)) & 0x01010101u;
+  asm("" : "+v"(t));   // opaque: otherwise the bytes are re-derived as single-bit extracts (shift + and + cvt each)
+  return f32x4{(float)(t & 0xffu), (float)((t >> 8) & 0xffu), (float)((t >> 16) & 0xffu), (float)(t >> 24)};
 }
-// Sign record of one (edge | pair): 64 lane words in lane order; bit 4*j+k of lane (h,g)'s word belongs to
-// feature h*F_out + (j*G+g)*4 + k, the float the lane owns in the P/Q/a rows.  4*QN bits per lane.
-template <int QN> struct SignWord { typedef uint32_t type; };
-template <> struct SignWord<4> { typedef uint16_t type; };
-template <> struct SignWord<2> { typedef uint8_t type; };
-template <> struct SignWord<1> { typedef uint8_t type; };
 
 __device__ __forceinline__ float dot4(const f32x4 a, const f32x4 b, float acc) {
   acc = fmaf(a.x, b.x, acc);

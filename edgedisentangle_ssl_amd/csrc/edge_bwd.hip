@@ -267,7 +267,7 @@ struct SignArgs {
   const float* g;        // [H][g_stride] upstream gradient of the raw scores
   int64_t g_stride;
   int h_lo, h_hi;
-  const void* sign;      // [M][64] SignWord<QN>
+  const uint32_t* sign;  // [M][64] sign words (disgat_common.h)
   const float* keyop;    // P (row pass) or Q (column pass); read only when ga_part != null
   int ld_key;
   const float* a;
@@ -281,14 +281,13 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void seg_grad_sign_kernel(const Si
   constexpr int GL = 6 - HL;
   constexpr int G = 1 << GL;
   constexpr int FQ = QN * G * 4;
-  typedef typename SignWord<QN>::type W;
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * DISGAT_WAVES_PER_BLOCK + (threadIdx.x >> 6);
   const int n_waves = gridDim.x * DISGAT_WAVES_PER_BLOCK;
   const int myh = lane >> GL;
   const bool active = (myh >= A.h_lo) && (myh < A.h_hi);
   const int qoff = myh * FQ + (lane & (G - 1)) * 4;
-  const W* sg = reinterpret_cast<const W*>(A.sign) + lane;
+  const uint32_t* sg = A.sign + lane;
   const float* gh = A.g + (int64_t)myh * A.g_stride;
   const bool want_ga = A.ga_part != nullptr;
 
@@ -321,10 +320,7 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void seg_grad_sign_kernel(const Si
           gall += gv[t];
 #pragma unroll
           for (int j = 0; j < QN; ++j) {
-            up[j].x = fmaf(gv[t], (float)((w[t] >> (4 * j + 0)) & 1u), up[j].x);
-            up[j].y = fmaf(gv[t], (float)((w[t] >> (4 * j + 1)) & 1u), up[j].y);
-            up[j].z = fmaf(gv[t], (float)((w[t] >> (4 * j + 2)) & 1u), up[j].z);
-            up[j].w = fmaf(gv[t], (float)((w[t] >> (4 * j + 3)) & 1u), up[j].w);
+            up[j] += gv[t] * sign_floats<QN>(w[t], j);      // shift, and, 4 v_cvt_f32_ubyteN, 2 v_pk_fma_f32
           }
         }
       }
@@ -541,7 +537,7 @@ extern "C" int disgat_seg_grad_att3(const int32_t* items, int n_items, const int
 }
 
 extern "C" int disgat_seg_grad_sign(const int32_t* items, int n_items, const int32_t* perm, const float* g,
-                                    int64_t g_stride, int h_lo, int h_hi, int H, int F_out, const void* sign_bits,
+                                    int64_t g_stride, int h_lo, int h_hi, int H, int F_out, const uint32_t* sign_bits,
                                     const float* keyop, int ld_key, const float* a, float* gkey, int ld_gkey,
                                     float* ga_part, int n_waves, disgat_stream_t stream) {
   using namespace disgat;

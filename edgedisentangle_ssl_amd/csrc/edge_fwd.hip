@@ -44,7 +44,7 @@ struct EdgeFwdArgs {
   float* part_den;
   int sage_div;
   DropCfg drop;
-  void* sign;           // att 3, optional: [E][64] sign words (disgat_common.h SignWord) for the backward pass
+  uint32_t* sign;       // att 3, optional: [E][64] sign words (disgat_common.h) for the backward pass
 };
 
 template <int ATT, int HL, int QN, int XN>
@@ -130,15 +130,10 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void edge_fwd_kernel(const EdgeFwd
     float e;
     if constexpr (ATT == 3 && SIGN) {
       float acc = 0.f;
-      uint32_t bits = 0u;
+      SignAcc sg;
 #pragma unroll
-      for (int j = 0; j < QN; ++j) {
-        const f32x4 z = p_r[j] + b.q[j];
-        acc = dot4_lrelu_z(a_r[j], z, acc);
-        bits |= sign4(z) << (4 * j);
-      }
-      typedef typename SignWord<QN>::type W;
-      reinterpret_cast<W*>(A.sign)[k * 64 + lane] = (W)bits;     // one 64-word row per edge, coalesced
+      for (int j = 0; j < QN; ++j) acc = dot4_lrelu_sign(a_r[j], p_r[j], b.q[j], acc, sg);
+      A.sign[k * 64 + lane] = sg.word();                         // one 64-word (256-B) row per edge, coalesced
       e = group_sum<GL>(acc);
     } else if constexpr (ATT == 3) {
       float acc = 0.f;
@@ -319,7 +314,7 @@ extern "C" int disgat_edge_fwd(int att, const int32_t* items, int n_items, const
                                int F_in, int F_out, const float* x, int ldx, const float* rowop, int ld_row,
                                const float* colop, int ld_col, const float* a, float* Z, float* edge_e, float* den,
                                float* part_z, float* part_den, int sage_div, float drop_p, uint64_t drop_seed,
-                               void* sign_bits, disgat_stream_t stream) {
+                               uint32_t* sign_bits, disgat_stream_t stream) {
   using namespace disgat;
   DISGAT_REQUIRE(att >= 1 && att <= 3, "edge_fwd: att=%d not in 1..3", att);
   DISGAT_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "edge_fwd: dropout p=%f outside [0,1)", (double)drop_p);

@@ -52,9 +52,8 @@ SIGN_BACKWARD = True
 
 
 def sign_record(att, H, F_out, count, dev):
-    """uint8 [count, 64*w] buffer for the att-3 sign words (layout: include/disgat_hip.h `sign_bits`)."""
-    qn = F_out // ((64 // H) * 4)
-    return torch.empty((count, 64 * {8: 4, 4: 2, 2: 1, 1: 1}[qn]), dtype=torch.uint8, device=dev)
+    """int32 [count, 64] buffer for the att-3 sign words (layout: include/disgat_hip.h `sign_bits`)."""
+    return torch.empty((count, 64), dtype=torch.int32, device=dev)
 
 
 def wants_sign(att, *operands):

@@ -39,12 +39,11 @@
  *   part_z / part_den   [n_slots][H][F_in] / [n_slots][2][H] partial records of split rows
  *   drop_p, drop_seed   attention dropout (layers.py:394): edge k, head h is kept iff the top 32 bits
  *                       of splitmix64(seed + (k*H+h)*0x9E3779B97F4A7C15) >= p*2^32; p = 0 disables it
- *   sign_bits           att 3 only, optional (NULL = not recorded): [E | M][64] words of 4*QN bits rounded up to
- *                       1, 2 or 4 bytes (QN = F_out / ((64/H)*4): QN 8 -> uint32, 4 -> uint16, 2 and 1 -> uint8).
- *                       Word l of a row belongs to lane l = (head h = l / G, g = l % G), G = 64/H; its bit
- *                       4*j+k is (P[row] + Q[col] > 0) at feature h*F_out + (j*G+g)*4 + k: which slope
- *                       leaky_relu took.  disgat_seg_grad_sign computes the score's backward from it
- *                       without gathering any operand row.
+ *   sign_bits           att 3 only, optional (NULL = not recorded): uint32 [E | M][64].  Word l of a row belongs
+ *                       to lane l = (head h = l / G, g = l % G), G = 64/H, QN = F_out / (4*G); its bit
+ *                       8*k + QN-1-j is (P[row] + Q[col] > 0) at feature h*F_out + (j*G+g)*4 + k (k < 4,
+ *                       j < QN): which slope leaky_relu took.  disgat_seg_grad_sign computes the score's
+ *                       backward from it without gathering any operand row.
  *   H must be a power of two (the host pads missing heads with zero weights).
  *
  * att (the reference's --att / att_type):
@@ -78,7 +77,7 @@ int disgat_edge_fwd(int att, const int32_t* items, int n_items, const int32_t* c
                     float* Z, float* edge_e, float* den,
                     float* part_z, float* part_den,
                     int sage_div, float drop_p, uint64_t drop_seed,
-                    void* sign_bits, disgat_stream_t stream);
+                    uint32_t* sign_bits, disgat_stream_t stream);
 
 /* Sums the partial records of split rows (in chunk order: deterministic) and normalises. */
 int disgat_edge_combine(const int32_t* split_rows, const int32_t* split_ptr, int n_split,
@@ -92,7 +91,7 @@ int disgat_aux_score(int att, const int64_t* pair_rows, const int64_t* pair_cols
                      const float* rowop, int ld_row,
                      const float* colop, int ld_col,
                      const float* a,
-                     float* out, void* sign_bits, disgat_stream_t stream);
+                     float* out, uint32_t* sign_bits, disgat_stream_t stream);
 
 /* Weighted squared-error partial sums of pred = sigmoid(sum_{h in [h_lo,h_hi)} aux[h][m])
  * against 0/1 labels: acc[0] += sum over positives, acc[1] += sum over zeros, acc[2] += #positives.
@@ -128,7 +127,7 @@ int disgat_seg_grad_att3(const int32_t* items, int n_items, const int32_t* other
  * The a-gradient of a list is the sum of the row-side pass (keyop = P) and the column-side pass (keyop = Q),
  * because lrelu(z) = lrelu'(z) * (P + Q).  Reads 64 words + H floats per list position. */
 int disgat_seg_grad_sign(const int32_t* items, int n_items, const int32_t* perm, const float* g,
-                         int64_t g_stride, int h_lo, int h_hi, int H, int F_out, const void* sign_bits,
+                         int64_t g_stride, int h_lo, int h_hi, int H, int F_out, const uint32_t* sign_bits,
                          const float* keyop, int ld_key, const float* a, float* gkey, int ld_gkey,
                          float* ga_part, int n_waves, disgat_stream_t stream);
 
