@@ -257,6 +257,37 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs G) {
 // ------------------------------------------------------------------------------------------
 #include "disgat_api.h"
 
+namespace disgat {
+// Backward of the fused epilogue activation from the saved OUTPUT: gin = g * act'(pre-activation), with
+// ELU' = (out > 0 ? 1 : out + 1) (out + 1 = exp(v) for v <= 0) and leaky' = (out > 0 ? 1 : slope).
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ g, const float* __restrict__ out,
+                                                      float* __restrict__ gin, int64_t n4, int act, float slope) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const f32x4 gv = ld4(g + i * 4), o = ld4(out + i * 4);
+    f32x4 r;
+    r.x = gv.x * (o.x > 0.f ? 1.f : (act == 1 ? o.x + 1.f : slope));
+    r.y = gv.y * (o.y > 0.f ? 1.f : (act == 1 ? o.y + 1.f : slope));
+    r.z = gv.z * (o.z > 0.f ? 1.f : (act == 1 ? o.z + 1.f : slope));
+    r.w = gv.w * (o.w > 0.f ? 1.f : (act == 1 ? o.w + 1.f : slope));
+    st4(gin + i * 4, r);
+  }
+}
+}  // namespace disgat
+
+extern "C" int disgat_act_bwd(const float* g, const float* out, float* gin, int64_t n, int act, float slope,
+                              disgat_stream_t stream) {
+  using namespace disgat;
+  if (n == 0) return 0;
+  DISGAT_REQUIRE(g && out && gin && n > 0 && n % 4 == 0, "act_bwd: null pointer or n %% 4 != 0");
+  DISGAT_REQUIRE(act == 1 || act == 2, "act_bwd: act=%d (1 = ELU, 2 = leaky ReLU)", act);
+  DISGAT_REQUIRE(aligned16(g) && aligned16(out) && aligned16(gin), "act_bwd: buffers must be 16-byte aligned");
+  const int64_t n4 = n / 4;
+  const int grid = (int)((n4 + 255) / 256 < 65536 ? (n4 + 255) / 256 : 65536);
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), g, out, gin, n4,
+                     act, slope);
+  return check_launch("act_bwd_kernel");
+}
+
 extern "C" int disgat_gemm_split(const float* A, int64_t lda, int64_t a_batch_stride, const uint16_t* Bt_planes,
                                  const float* bias, const float* init, int64_t ldi, int64_t init_batch_stride, float* C,
                                  int64_t ldc, int64_t c_batch_stride, int M, int N, int K, int batch, int act,

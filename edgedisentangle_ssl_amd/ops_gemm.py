@@ -77,6 +77,17 @@ def _forward(a, w, bias, init, act, slope):
     return out
 
 
+def _act_backward(g, out, act, slope):
+    """g * act'(.) from the saved output in one pass (csrc/gemm_split.hip: act_bwd_kernel)."""
+    g = g.contiguous()
+    if not (g.is_cuda and out.is_contiguous() and g.numel() % 4 == 0 and g.data_ptr() % 16 == 0):
+        neg = out + 1.0 if act == ACT_ELU else torch.full_like(out, slope)
+        return g * torch.where(out > 0, torch.ones_like(out), neg)
+    gin = torch.empty_like(g)
+    _lib.call("disgat_act_bwd", g.data_ptr(), out.data_ptr(), gin.data_ptr(), g.numel(), act, float(slope), ops._stream())
+    return gin
+
+
 class _Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, w, bias, init, act, slope):
@@ -89,21 +100,22 @@ class _Linear(torch.autograd.Function):
     def backward(ctx, g):
         a, w, out = ctx.saved_tensors
         act, slope, has_bias, has_init = ctx.meta
-        if act == ACT_ELU:
-            g = g * torch.where(out > 0, torch.ones_like(out), out + 1.0)
-        elif act == ACT_LEAKY:
-            g = g * torch.where(out > 0, torch.ones_like(out), torch.full_like(out, slope))
+        if act != ACT_NONE:
+            g = _act_backward(g, out, act, slope)
         ga = gw = gb = gi = None
+        # grad of the data operand: the same split-bf16 GEMM with the transposed weight (falls back to hipBLASLt
+        # through _forward's own shape check); the weight gradient reduces over the million-row dimension and
+        # stays on hipBLASLt.
         if a.dim() == 3:
-            hb, m, _ = a.shape
+            hb, m, k = a.shape
             g3 = g.view(m, hb, -1).permute(1, 0, 2)
             if ctx.needs_input_grad[0]:
-                ga = torch.bmm(g3, w.transpose(1, 2))
+                ga = _forward(g3, w.transpose(1, 2), None, None, ACT_NONE, 0.0).view(m, hb, k).permute(1, 0, 2)
             if ctx.needs_input_grad[1]:
                 gw = torch.bmm(a.transpose(1, 2), g3)
         else:
             if ctx.needs_input_grad[0]:
-                ga = g @ w.t()
+                ga = _forward(g, w.t(), None, None, ACT_NONE, 0.0)
             if ctx.needs_input_grad[1]:
                 gw = a.t() @ g
         if has_bias and ctx.needs_input_grad[2]:

@@ -152,6 +152,11 @@ int disgat_gemm_split(const float* A, int64_t lda, int64_t a_batch_stride, const
                       int64_t ldc, int64_t c_batch_stride, int M, int N, int K, int batch, int act,
                       float slope, int terms, disgat_stream_t stream);
 
+/* Backward of the epilogue activation from the saved output (n contiguous floats, n % 4 == 0):
+ * gin = g * (out > 0 ? 1 : (act == 1 ? out + 1 : slope)); act 1 = ELU, 2 = leaky ReLU.  gin may alias g. */
+int disgat_act_bwd(const float* g, const float* out, float* gin, int64_t n, int act, float slope,
+                   disgat_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
