@@ -11,9 +11,20 @@ def _buf(shape, dev, zero):
     return (torch.zeros if zero else torch.empty)(shape, dtype=torch.float32, device=dev)
 
 
+def _keybuf(shape, dev, wi, force_zero=False):
+    """Output rows of a segment pass: whole keys are stored, keys split across work items are accumulated with
+    atomics, so only THOSE rows need zeroing (a handful of hub rows, not the whole multi-GB buffer)."""
+    if force_zero:
+        return _buf(shape, dev, True)
+    out = _buf(shape, dev, False)
+    if wi.n_split > 0:
+        out.index_fill_(0, wi.split_rows.long(), 0.0)
+    return out
+
+
 def _seg_att3(wi, other, perm, g, lo, hi, H, f_out, keyop, otherop, a, n_keys, want_ga):
     dev = g.device
-    gkey = _buf((n_keys, H * f_out), dev, wi.n_split > 0)
+    gkey = _keybuf((n_keys, H * f_out), dev, wi)
     n_waves = min(_MAX_WAVES, (wi.n_items + 3) // 4 * 4)
     ga_part = torch.empty((n_waves, H * f_out), dtype=torch.float32, device=dev) if want_ga else None
     _lib.call("disgat_seg_grad_att3", wi.items.data_ptr(), wi.n_items, other.data_ptr(), ops._ptr(perm), g.data_ptr(),
@@ -26,7 +37,7 @@ def _seg_sign(wi, perm, g, lo, hi, H, f_out, sign, keyop, a, n_keys, want_ga):
     """Score backward of one side (rows: keyop = P, columns: keyop = Q) from the forward's sign record.
     Returns (gkey [n_keys, H*f_out], this side's share of grad a or None)."""
     dev = g.device
-    gkey = _buf((n_keys, H * f_out), dev, wi.n_split > 0)
+    gkey = _keybuf((n_keys, H * f_out), dev, wi)
     n_waves = min(_MAX_WAVES, (wi.n_items + 3) // 4 * 4)
     ga_part = torch.empty((n_waves, H * f_out), dtype=torch.float32, device=dev) if want_ga else None
     _lib.call("disgat_seg_grad_sign", wi.items.data_ptr(), wi.n_items, ops._ptr(perm), g.data_ptr(), g.stride(0), lo, hi,
@@ -72,7 +83,7 @@ def edge_backward(ctx, gz, ge):
                 0, graph.col.long(), ge_tot.t())
     elif att == 2:
         if need_row:                                    # gP[r,h,:] = sum_k ge_k x[col_k]
-            g_row = _buf((n, H * f_in), dev, wi.n_split > 0)
+            g_row = _keybuf((n, H * f_in), dev, wi)
             _seg_hx(0, wi, graph.col, None, ge_tot, 0, H, H, f_in, x, g_row, False)
     elif sign is not None:                              # gather-free: both sides read the sign record
         if need_row or need_a:
@@ -86,7 +97,7 @@ def edge_backward(ctx, gz, ge):
         if need_col:
             g_col, _ = _seg_att3(twi, t.col, t.eid, ge_tot, 0, H, H, f_out, colop, rowop, a, colop.shape[0], False)
     if need_x:
-        g_x = _buf(tuple(x.shape), dev, twi.n_split > 0 or x.stride(0) != f_in)
+        g_x = _keybuf(tuple(x.shape), dev, twi, x.stride(0) != f_in)
         # grad of the aggregation: gx[c] = sum_{k in col c} sum_h beta_kh gZ[row_k,h,:]
         _seg_hx(1, twi, t.col, t.eid, beta, 0, H, H, f_in, gz.view(n, H * f_in), g_x, False)   # n rows of gZ, g_x over all columns
         if att == 2:                                    # e = <P[r,h,:], x[c,:]>  ->  gx[c] += sum_h ge_kh P[r_k,h,:]
@@ -145,7 +156,7 @@ def aux_backward(ctx, gout):
         if att == 3:
             g_row, g_a = _seg_att3(wi, other, perm32, gout, lo, hi, H, f_out, rowop, colop, a, n_rows, need_a)
         else:
-            g_row = _buf((n_rows, H * f_in), dev, wi.n_split > 0)
+            g_row = _keybuf((n_rows, H * f_in), dev, wi)
             _seg_hx(0, wi, other, perm32, gout, lo, hi, H, f_in, x, g_row, False)
     if (att == 3 and need_col) or (att == 2 and need_x):
         wi, perm, perm32 = _segments(cols, n_cols, chunk)
@@ -153,6 +164,6 @@ def aux_backward(ctx, gout):
         if att == 3:
             g_col, _ = _seg_att3(wi, other, perm32, gout, lo, hi, H, f_out, colop, rowop, a, n_cols, False)
         else:
-            g_x = _buf(tuple(x.shape), dev, wi.n_split > 0 or x.stride(0) != f_in)
+            g_x = _keybuf(tuple(x.shape), dev, wi, x.stride(0) != f_in)
             _seg_hx(1, wi, other, perm32, gout, lo, hi, H, f_in, rowop, g_x, False)
     return g_x, g_row, g_col, g_a, None, None

@@ -1,7 +1,8 @@
 """Dense contractions of the DISGAT path on the split-bf16 MFMA GEMM (csrc/gemm_split.hip).
 
 `linear(a, w, ...)` computes act(a @ w + bias + init) for a 2-D `a`, or for a head-batched view
-`a` [H, M, K] with `w` [H, K, N] writing the concatenated-heads layout [M, H*N].  Shapes outside
+`a` [H, M, K] with `w` [H, K, N] writing the concatenated-heads layout [M, H*N] (`init` is then
+[M, H*N], or [M, N] shared by every head).  Shapes outside
 the kernel's tiling (N % 128, K % 32) and DISGAT_GEMM=blas go to hipBLASLt through torch.matmul -
 still the GPU, still fp32.  DISGAT_GEMM=split3 selects the 3-product variant (not fp32-accurate;
 benchmark switch only).
@@ -62,16 +63,19 @@ def _forward(a, w, bias, init, act, slope):
             if bias is not None:
                 out = out + bias
         if init is not None:
-            out = out + init
+            out = out + (init.repeat(1, hb) if batched and init.shape == (m, n) and hb > 1 else init)
         return _apply_act(out, act, slope)
     out = torch.empty((m, hb * n), dtype=torch.float32, device=a.device)
     planes = split_weight(w)
-    if init is not None and (init.stride(-1) != 1 or init.shape != out.shape):
+    init_bs = n if batched else 0
+    if init is not None and batched and init.shape == (m, n) and init.stride(-1) == 1:
+        init_bs = 0                                  # one [M,N] init shared by all heads: batch stride 0
+    elif init is not None and (init.stride(-1) != 1 or init.shape != out.shape):
         init = init.expand(m, hb * n).contiguous()
     if bias is not None:
         bias = bias.contiguous()
     _lib.call("disgat_gemm_split", a.data_ptr(), a.stride(-2), a.stride(0) if batched else 0, planes.data_ptr(),
-              ops._ptr(bias), ops._ptr(init), 0 if init is None else init.stride(0), n if batched else 0,
+              ops._ptr(bias), ops._ptr(init), 0 if init is None else init.stride(0), init_bs,
               out.data_ptr(), out.stride(0), n if batched else 0, m, n, k, hb, act, float(slope),
               3 if mode() == "split3" else 6, ops._stream())
     return out
@@ -94,6 +98,7 @@ class _Linear(torch.autograd.Function):
         out = _forward(a, w, bias, init, act, slope)
         ctx.save_for_backward(a, w, out if act != ACT_NONE else None)
         ctx.meta = (act, slope, bias is not None, init is not None)
+        ctx.init_shared = init is not None and a.dim() == 3 and init.shape[1] != out.shape[1]
         return out
 
     @staticmethod
@@ -121,7 +126,7 @@ class _Linear(torch.autograd.Function):
         if has_bias and ctx.needs_input_grad[2]:
             gb = g.sum(0)
         if has_init and ctx.needs_input_grad[3]:
-            gi = g
+            gi = g.view(g.shape[0], a.shape[0], -1).sum(1) if ctx.init_shared else g
         return ga, gw, gb, gi, None, None
 
 

@@ -39,7 +39,10 @@ def pair_mse_loss(aux, h_lo, h_hi, labels, graph=None):
         m = acc[3]
         neg_w = acc[2] / (m * m - acc[2])
         return ((acc[0] + neg_w * acc[1]) / m).to(torch.float32)
-    pred = torch.sigmoid(torch.sum(torch.stack(heads), dim=0)).squeeze(-1)
+    if fused:       # the heads are rows of one [H,M] score buffer: sum the rows in place (no stack, one gradient slice)
+        pred = torch.sigmoid(base[h_lo:h_hi].sum(0))
+    else:
+        pred = torch.sigmoid(torch.sum(torch.stack(heads), dim=0)).squeeze(-1)
     if not sharded:
         return adj_mse_loss(pred, labels)
     # sharded + autograd: class weights and the mean use GLOBAL counts; this rank contributes the
@@ -225,8 +228,29 @@ class DifHeadTrainer(Trainer):
         for layer, (inp, heads) in enumerate(((r["x"], r["heads"][0]), (r["feature_1"], r["heads"][1]))):
             classifier = self.classifier1 if layer == 0 else self.classifier2
             mods = list(classifier.model)
+            fused = getattr(heads, "fused", None)
             if len(mods) < 3 or not isinstance(mods[0], torch.nn.Linear):     # cls_layer == 1: no shared part
                 outs = [classifier(torch.cat((inp, h), dim=-1), cls=True) for h in heads]
+            elif fused is not None and isinstance(mods[1], torch.nn.LeakyReLU) and fused.shape[1] == len(heads) * heads[0].shape[1]:
+                # all heads in one batched GEMM on the fused [N, H*nhid] buffer: no per-head slices in the autograd
+                # graph (each slice's backward zero-fills and re-adds a full [N, H*nhid] gradient)
+                lin = mods[0]
+                f_in, nh, fo = inp.shape[1], len(heads), heads[0].shape[1]
+                shared = ops_gemm.linear(inp, lin.weight[:, :f_in].t(), lin.bias)
+                w_h = lin.weight[:, f_in:].t().unsqueeze(0).expand(nh, fo, -1)
+                t = ops_gemm.linear(fused.view(-1, nh, fo).permute(1, 0, 2), w_h, None, shared, ops_gemm.ACT_LEAKY,
+                                    mods[1].negative_slope)                     # [N, H*hidden]
+                t = t.view(t.shape[0] * nh, -1)
+                for m in mods[2:]:
+                    t = m(t)
+                diag = F.log_softmax(t, dim=1).view(-1, nh, t.shape[1]).diagonal(dim1=1, dim2=2)   # logp[n, i, i]
+                if sharded:
+                    loc = -diag.sum() / g.n_global
+                    term = loc + (parallel.all_reduce_sum(loc.detach().clone(), g) - loc.detach())
+                else:
+                    term = -diag.mean(0).sum()
+                loss = term if loss is None else loss + term
+                continue
             else:
                 lin = mods[0]
                 f_in = inp.shape[1]
