@@ -102,6 +102,10 @@ _SIGS = {
     "disgat_gemm_split": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _P, _P, _P, _c.c_int64, _c.c_int64, _P, _c.c_int64,
                                      _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_float,
                                      _c.c_int, _P]),
+    "disgat_gemm_f16x3": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _P, _P, _P, _P, _P, _c.c_int64, _c.c_int64, _P,
+                                     _c.c_int64, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
+                                     _c.c_float, _P]),
+    "disgat_amax": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _P, _P]),
     "disgat_act_bwd": (_c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int, _c.c_float, _P]),
 }
 

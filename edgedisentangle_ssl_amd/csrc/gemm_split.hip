@@ -33,6 +33,7 @@
 // blocks/CU).  Block ids are remapped so that all N-tiles of one M-tile run on one XCD (A tile
 // served by that XCD's L2).  Epilogue fuses bias, an additive init matrix and ELU / leaky-ReLU.
 #include "disgat_common.h"
+#include <type_traits>
 
 namespace disgat {
 
@@ -252,6 +253,397 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs G) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Second scheme, half the MFMA work: two fp16 planes per operand instead of three bf16 planes.
+//   t = v * s (s = power of two placing the operand's largest magnitude in [2^13, 2^14)),
+//   hi = fp16(t), lo = fp16((t - hi) * 2^11)         both round-to-nearest, t - hi exact in fp32
+// so t = hi + lo * 2^-11 up to 2^-23 |t| for every element whose hi is a normal fp16 (within 2^-27 of the
+// operand's maximum) - one bit short of fp32's own 2^-24 representation error.  A product needs hi*hi and the
+// two cross terms (lo*lo is 2^-24 relative): 3 MFMAs instead of 6.  The cross terms carry a 2^-11 weight
+// and accumulate in their own fp32 accumulator (folding the weight into lo would push lo into fp16's
+// subnormal range for all but the largest elements).  C = (acc_hh + 2^-11 acc_x) / (s_A s_B).
+// Measured error vs fp64: tests/test_gpu_gemm.py (yardstick hipBLASLt fp32).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+struct GemmHArgs {
+  const float* A;
+  int64_t lda, a_bs;
+  const uint16_t* Bt;    // [batch][2][N][K] fp16: hi, lo of (B^T * s_B), k contiguous
+  const float* a_amax;   // device scalar: max |A| over the whole operand (disgat_amax)
+  const float* b_scale;  // device scalar: s_B used for Bt
+  const float* bias;
+  const float* init;
+  int64_t ldi, i_bs;
+  float* C;
+  int64_t ldc, c_bs;
+  int M, N, K, batch;
+  int act;
+  float slope;
+  int mt, nt;
+};
+
+// power-of-two scale that places amax in [2^13, 2^14); 1 for zero / non-finite input
+__device__ __forceinline__ float f16_scale(float amax) {
+  if (!(amax > 0.f) || !(amax < 3.0e38f)) return 1.0f;
+  int e;
+  (void)frexpf(amax, &e);                       // amax = m * 2^e, m in [0.5, 1)
+  e = max(-100, min(100, e));
+  return ldexpf(1.0f, 14 - e);
+}
+
+__device__ __forceinline__ uint32_t pack_f16(float a, float b) {
+  const f16x2 h = {(_Float16)a, (_Float16)b};
+  return *reinterpret_cast<const uint32_t*>(&h);
+}
+
+// split 4 floats (already scaled) into hi / lo fp16 planes, packed 2 x uint32 each
+__device__ __forceinline__ void split4h(const f32x4 t, u32x2& hi, u32x2& lo) {
+  const _Float16 h0 = (_Float16)t.x, h1 = (_Float16)t.y, h2 = (_Float16)t.z, h3 = (_Float16)t.w;
+  const f16x2 a = {h0, h1}, b = {h2, h3};
+  hi = u32x2{*reinterpret_cast<const uint32_t*>(&a), *reinterpret_cast<const uint32_t*>(&b)};
+  lo = u32x2{pack_f16((t.x - (float)h0) * 2048.f, (t.y - (float)h1) * 2048.f),
+             pack_f16((t.z - (float)h2) * 2048.f, (t.w - (float)h3) * 2048.f)};
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(const GemmHArgs G) {
+  __shared__ __attribute__((aligned(16))) uint16_t lds[17408];      // 4 planes (32 KB) | epilogue stage (33.8 KB)
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int b = blockIdx.x;
+  const int xcd = b & 7, q = b >> 3;
+  const int m_tile = (q / G.nt) * 8 + xcd;
+  const int n_tile = q % G.nt;
+  if (m_tile >= G.mt) return;
+  const int bz = blockIdx.y;
+  const int m0 = m_tile * GBM, n0 = n_tile * GBN;
+
+  const float* A = G.A + (int64_t)bz * G.a_bs;
+  const uint16_t* Bt = G.Bt + (int64_t)bz * 2 * G.N * G.K;
+  float* C = G.C + (int64_t)bz * G.c_bs;
+  const float sA = f16_scale(*G.a_amax);
+  const float inv = 1.0f / (sA * *G.b_scale);
+
+  const int a_row = tid >> 3, a_col = (tid & 7) * 4;
+  const int b_row = tid >> 2, b_col = (tid & 3) * 8;
+  // A (HBM) is prefetched two tiles ahead, B (the small weight, L2-resident) one tile ahead: 48 staging registers
+  f32x4 a_s0[4], a_s1[4];
+  u32x4 b_s[4];
+
+  auto load_a = [&](f32x4(&a_st)[4], int kt) {
+    const int k0 = kt * GBK;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = m0 + a_row + 32 * i;
+      a_st[i] = (r < G.M) ? ld4(A + (int64_t)r * G.lda + k0 + a_col) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto load_b = [&](u32x4(&b_st)[4], int kt) {
+    const int k0 = kt * GBK;
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int n = n0 + b_row + 64 * i;
+        b_st[p * 2 + i] = *reinterpret_cast<const u32x4*>(Bt + ((int64_t)p * G.N + n) * G.K + k0 + b_col);
+      }
+  };
+  auto store_tiles = [&](const f32x4(&a_st)[4], const u32x4(&b_st)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      u32x2 h, l;
+      split4h(a_st[i] * sA, h, l);
+      const int o = sw(a_row + 32 * i, a_col >> 3) + (a_col & 4);
+      *reinterpret_cast<u32x2*>(&lds[0 * PLANE + o]) = h;
+      *reinterpret_cast<u32x2*>(&lds[1 * PLANE + o]) = l;
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        *reinterpret_cast<u32x4*>(&lds[(2 + p) * PLANE + sw(b_row + 64 * i, b_col >> 3)]) = b_st[p * 2 + i];
+  };
+
+  f32x4v acc[4][4], acx[4][4];      // hi*hi | hi*lo + lo*hi (weight 2^-11)
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+      acx[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    }
+
+  const int frag_off = sw(lane & 15, lane >> 4);
+  const int KT = G.K / GBK;
+
+  auto compute = [&]() {
+    // the hi fragments stay live for all three products; the lo fragments are streamed one at a time
+    f16x8 ah[4], bh[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ah[i] = *reinterpret_cast<const f16x8*>(&lds[0 * PLANE + (wm * 64 + i * 16) * GLD + frag_off]);
+      bh[i] = *reinterpret_cast<const f16x8*>(&lds[2 * PLANE + (wn * 64 + i * 16) * GLD + frag_off]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f16x8 bl = *reinterpret_cast<const f16x8*>(&lds[3 * PLANE + (wn * 64 + j * 16) * GLD + frag_off]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl, acx[i][j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f16x8 al = *reinterpret_cast<const f16x8*>(&lds[1 * PLANE + (wm * 64 + i * 16) * GLD + frag_off]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[j], acx[i][j], 0, 0, 0);
+    }
+  };
+
+  load_a(a_s0, 0);
+  load_b(b_s, 0);
+  store_tiles(a_s0, b_s);
+  if (KT > 1) load_a(a_s1, 1);
+  __syncthreads();
+  for (int kt = 0; kt < KT; kt += 2) {
+    if (kt + 2 < KT) load_a(a_s0, kt + 2);
+    if (kt + 1 < KT) load_b(b_s, kt + 1);
+    compute();
+    __syncthreads();
+    if (kt + 1 < KT) {
+      store_tiles(a_s1, b_s);
+      __syncthreads();
+      if (kt + 3 < KT) load_a(a_s1, kt + 3);
+      if (kt + 2 < KT) load_b(b_s, kt + 2);
+      compute();
+      __syncthreads();
+      if (kt + 2 < KT) {
+        store_tiles(a_s0, b_s);
+        __syncthreads();
+      }
+    }
+  }
+
+  const float* bias = G.bias ? G.bias + (int64_t)bz * G.N : nullptr;
+  const float* init = G.init ? G.init + (int64_t)bz * G.i_bs : nullptr;
+  float* stage = reinterpret_cast<float*>(lds);
+  constexpr int SLD = GBN + 4;
+  const float xw = inv * (1.0f / 2048.f);
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    if (wm == half) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            stage[(i * 16 + (lane >> 4) * 4 + r) * SLD + wn * 64 + j * 16 + (lane & 15)] =
+                fmaf(acx[i][j][r], xw, acc[i][j][r] * inv);
+    }
+    __syncthreads();
+    const int c4 = (tid & 31) * 4;
+    const int col = n0 + c4;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (bias) bv = ld4(bias + col);
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      const int lr = (tid >> 5) + rr * 8;
+      const int row = m0 + half * 64 + lr;
+      if (row < G.M) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(&stage[lr * SLD + c4]) + bv;
+        if (init) v += ld4(init + (int64_t)row * G.ldi + col);
+        v.x = act_fn(v.x, G.act, G.slope); v.y = act_fn(v.y, G.act, G.slope);
+        v.z = act_fn(v.z, G.act, G.slope); v.w = act_fn(v.w, G.act, G.slope);
+        st4(C + (int64_t)row * G.ldc + col, v);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// A-stationary variant for K <= 256 (the P/Q, per-head projection and classifier GEMMs).  Ablation of the tiled
+// kernel above on [1e6,256] x [256,2048] (6.0 ms): the MFMAs account for 0.5 ms, re-reading the A tile once per
+// 128-column tile for 1.9 ms, the LDS-staged epilogue for 2.5 ms, and the phases hardly overlap.  Here a 512-thread
+// block keeps its whole 128 x K A tile, split once, in LDS (2 planes x 128 x (K+8) fp16 = 132 KB at K = 256) and
+// sweeps all N columns in steps of 256: wave w owns the 128 x 32 strip [32w, 32w+32) of the step, reads A fragments
+// from LDS and B fragments straight from global memory (the weight planes are L2-resident, k contiguous = the
+// MFMA B layout; one k-step prefetched), and stores its results directly - after one v_permlane32_swap per register
+// pair every store instruction writes two full 128-B rows.  No barrier after the A tile is in place.
+constexpr int AS_BM = 128, AS_PAD = 8;     // LDS row = K + 8 fp16: row stride = 4 banks mod 64 -> conflict-free b128 reads
+
+template <int ACT>
+__device__ __forceinline__ float act_ct(float v, float slope) {
+  if (ACT == 1) return v > 0.f ? v : __expf(v) - 1.0f;
+  if (ACT == 2) return v > 0.f ? v : slope * v;
+  return v;
+}
+
+template <int ACT>
+__global__ __launch_bounds__(512, 1) void gemm_f16x3_as_kernel(const GemmHArgs G) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t lds_as[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int bz = blockIdx.y;
+  const int m0 = blockIdx.x * AS_BM;
+  const int K = G.K, KP = K + AS_PAD, K4 = K >> 2;
+  const int plane = AS_BM * KP;
+
+  const float* A = G.A + (int64_t)bz * G.a_bs;
+  const uint16_t* Bt = G.Bt + (int64_t)bz * 2 * G.N * K;
+  float* C = G.C + (int64_t)bz * G.c_bs;
+  const float* bias = G.bias ? G.bias + (int64_t)bz * G.N : nullptr;
+  const float* init = G.init ? G.init + (int64_t)bz * G.i_bs : nullptr;
+  const float sA = f16_scale(*G.a_amax);
+  const float inv = 1.0f / (sA * *G.b_scale);
+  const float xw = inv * (1.0f / 2048.f);
+
+  // ---- A tile: fp32 -> scaled hi / lo planes in LDS, 8 float4 loads in flight per thread
+  const int n_f4 = AS_BM * K4;
+  for (int base = 0; base < n_f4; base += 512 * 8) {
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = base + u * 512 + tid;
+      const int r = idx / K4, c4 = idx - r * K4;
+      v[u] = (idx < n_f4 && m0 + r < G.M) ? ld4(A + (int64_t)(m0 + r) * G.lda + c4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = base + u * 512 + tid;
+      if (idx < n_f4) {
+        const int r = idx / K4, c4 = idx - r * K4;
+        u32x2 h, l;
+        split4h(v[u] * sA, h, l);
+        *reinterpret_cast<u32x2*>(&lds_as[r * KP + c4 * 4]) = h;
+        *reinterpret_cast<u32x2*>(&lds_as[plane + r * KP + c4 * 4]) = l;
+      }
+    }
+  }
+  __syncthreads();
+
+  const int KT = K / GBK;
+  const int a_off = (lane & 15) * KP + (lane >> 4) * 8;            // + i*16*KP + t*32 (+ plane)
+  const int64_t b_off = (int64_t)(lane & 15) * K + (lane >> 4) * 8;  // + (n + j*16)*K + t*32 (+ plane N*K)
+  const int64_t b_plane = (int64_t)G.N * K;
+  const int ocol = 16 * (lane >> 5) + (lane & 15);                  // output column inside the wave's 32-wide strip
+  const int orow = 4 * ((lane >> 4) & 1);                           // + 16*i + 8*s + r
+
+  for (int ns = 0; ns * 256 < G.N; ++ns) {
+    const int n_w = ns * 256 + wave * 32;
+    if (n_w >= G.N) break;                                          // N % 256 == 128: waves 4-7 idle in the last step
+    f32x4v acc[8][2], acx[8][2];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        acx[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+      }
+    const uint16_t* bp = Bt + (int64_t)n_w * K + b_off;
+    f16x8 bh_n[2], bl_n[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      bh_n[j] = *reinterpret_cast<const f16x8*>(bp + (int64_t)j * 16 * K);
+      bl_n[j] = *reinterpret_cast<const f16x8*>(bp + b_plane + (int64_t)j * 16 * K);
+    }
+    for (int t = 0; t < KT; ++t) {
+      f16x8 bh[2], bl[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        bh[j] = bh_n[j];
+        bl[j] = bl_n[j];
+      }
+      if (t + 1 < KT) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          bh_n[j] = *reinterpret_cast<const f16x8*>(bp + (int64_t)j * 16 * K + (t + 1) * GBK);
+          bl_n[j] = *reinterpret_cast<const f16x8*>(bp + b_plane + (int64_t)j * 16 * K + (t + 1) * GBK);
+        }
+      }
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {          // 4 row tiles at a time: 16 + 4 fragment registers live
+        f16x8 ah[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          ah[i] = *reinterpret_cast<const f16x8*>(&lds_as[a_off + (half * 4 + i) * 16 * KP + t * GBK]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            acc[half * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc[half * 4 + i][j], 0, 0, 0);
+            acx[half * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acx[half * 4 + i][j], 0, 0, 0);
+          }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const f16x8 al = *reinterpret_cast<const f16x8*>(&lds_as[plane + a_off + (half * 4 + i) * 16 * KP + t * GBK]);
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acx[half * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[j], acx[half * 4 + i][j], 0, 0, 0);
+        }
+      }
+    }
+    // ---- epilogue: C/D layout col = lane & 15, row = 4*(lane >> 4) + r.  Swapping the upper half of tile j=0
+    // with the lower half of tile j=1 leaves every register with 2 rows x 32 columns: full 128-B stores.
+    // Addresses: one per-lane pointer per N-step plus a uniform row offset (one 64-bit add per store; the row
+    // strides are made opaque per step, otherwise the 64 loop-invariant row offsets are hoisted out of the N loop and
+    // spilled); the activation is a template parameter (a run-time switch computed every branch for every element);
+    // ragged last tiles take the checked copy of the loop.  Before these changes the epilogue's ~16 VALU ops per
+    // element outweighed the MFMAs of the whole N-step.
+    const int col = n_w + ocol;
+    const float bv = bias ? bias[col] : 0.f;
+    int64_t ldc = G.ldc, ldi = G.ldi;
+    asm volatile("" : "+s"(ldc), "+s"(ldi));
+    float* cp = C + (int64_t)(m0 + orow) * ldc + col;
+    const float* ip = init ? init + (int64_t)(m0 + orow) * ldi + col : nullptr;
+    const bool full = m0 + AS_BM <= G.M;
+    auto emit = [&](auto checked) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v0 = fmaf(acx[i][0][r], xw, acc[i][0][r] * inv);
+          const float v1 = fmaf(acx[i][1][r], xw, acc[i][1][r] * inv);
+          const auto sw2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v0), __float_as_uint(v1), false, false);
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            const int dr = 16 * i + 8 * s2 + r;
+            if (!decltype(checked)::value || m0 + dr + orow < G.M) {
+              float v = __uint_as_float(sw2[s2]) + bv;
+              if (init) v += ip[dr * ldi];                                     // uniform test
+              cp[dr * ldc] = act_ct<ACT>(v, G.slope);
+            }
+          }
+        }
+    };
+    if (full) emit(std::false_type{});
+    else emit(std::true_type{});
+  }
+}
+
+// max |A| over a (batched, strided) fp32 operand into *out (a device float the caller zeroed): the bit pattern
+// of a non-negative float orders like an unsigned integer, so the reduction is one atomicMax per wave.
+__global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ A, int64_t lda, int64_t a_bs, int64_t rows,
+                                                   int M, int K4, uint32_t* __restrict__ out) {
+  uint32_t m = 0u;
+  const int64_t total = rows * K4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / K4;
+    const int c = (int)(i - r * K4) * 4;
+    const int64_t bz = r / M, rm = r - bz * M;
+    const f32x4 v = ld4(A + bz * a_bs + rm * lda + c);
+    m = max(max(m, __float_as_uint(fabsf(v.x))), max(__float_as_uint(fabsf(v.y)), max(__float_as_uint(fabsf(v.z)), __float_as_uint(fabsf(v.w)))));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+  if ((threadIdx.x & 63) == 0 && m != 0u) atomicMax(out, m);
+}
+
 }  // namespace disgat
 
 // ------------------------------------------------------------------------------------------
@@ -309,4 +701,55 @@ extern "C" int disgat_gemm_split(const float* A, int64_t lda, int64_t a_batch_st
   else
     hipLaunchKernelGGL(gemm_split_kernel<3>, dim3((unsigned)blocks, batch), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), G);
   return check_launch("gemm_split_kernel");
+}
+
+extern "C" int disgat_amax(const float* A, int64_t lda, int64_t a_batch_stride, int M, int K, int batch, float* out,
+                           disgat_stream_t stream) {
+  using namespace disgat;
+  if (M == 0 || batch == 0 || K == 0) return 0;
+  DISGAT_REQUIRE(A && out && M > 0 && K > 0 && batch > 0, "amax: null pointer / bad sizes");
+  DISGAT_REQUIRE(K % 4 == 0 && lda % 4 == 0 && a_batch_stride % 4 == 0 && aligned16(A), "amax: K, lda and the batch stride must be multiples of 4, A 16-byte aligned");
+  const int64_t rows = (int64_t)M * batch;
+  const int64_t work = rows * (K / 4);
+  const int grid = (int)(work / 256 + 1 < 8192 ? work / 256 + 1 : 8192);
+  hipLaunchKernelGGL(amax_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), A, lda, a_batch_stride,
+                     rows, M, K / 4, reinterpret_cast<uint32_t*>(out));
+  return check_launch("amax_kernel");
+}
+
+extern "C" int disgat_gemm_f16x3(const float* A, int64_t lda, int64_t a_batch_stride, const uint16_t* Bt_planes,
+                                 const float* a_amax, const float* b_scale, const float* bias, const float* init,
+                                 int64_t ldi, int64_t init_batch_stride, float* C, int64_t ldc, int64_t c_batch_stride,
+                                 int M, int N, int K, int batch, int act, float slope, disgat_stream_t stream) {
+  using namespace disgat;
+  if (M == 0 || batch == 0) return 0;
+  DISGAT_REQUIRE(A && Bt_planes && C && a_amax && b_scale && M > 0 && batch > 0, "gemm_f16x3: null pointer / bad sizes");
+  DISGAT_REQUIRE(N > 0 && N % GBN == 0 && K > 0 && K % GBK == 0, "gemm_f16x3: N=%d must be a multiple of %d and K=%d of %d", N, GBN, K, GBK);
+  DISGAT_REQUIRE(lda % 4 == 0 && a_batch_stride % 4 == 0 && aligned16(A) && aligned16(Bt_planes),
+                 "gemm_f16x3: A rows must be 16-byte aligned (lda, batch stride multiples of 4)");
+  DISGAT_REQUIRE(act >= 0 && act <= 2, "gemm_f16x3: act must be 0 (none), 1 (elu) or 2 (leaky relu)");
+  GemmHArgs G{A, lda, a_batch_stride, Bt_planes, a_amax, b_scale, bias, init, ldi, init_batch_stride, C, ldc,
+              c_batch_stride, M, N, K, batch, act, slope, (M + GBM - 1) / GBM, N / GBN};
+  const int64_t blocks = (int64_t)((G.mt + 7) / 8) * 8 * G.nt;
+  DISGAT_REQUIRE(blocks < ((int64_t)1 << 31) && batch < 65536, "gemm_f16x3: grid too large");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (K <= 256) {                       // A-stationary: the whole 128 x K A tile lives in LDS (dynamic, > 64 KB)
+    const int lds_bytes = 2 * AS_BM * (K + AS_PAD) * (int)sizeof(uint16_t);
+    static int lds_set = 0;
+    if (lds_set < lds_bytes) {
+      for (const void* f : {reinterpret_cast<const void*>(gemm_f16x3_as_kernel<0>), reinterpret_cast<const void*>(gemm_f16x3_as_kernel<1>),
+                            reinterpret_cast<const void*>(gemm_f16x3_as_kernel<2>)}) {
+        const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e != hipSuccess) return fail((int)e, "gemm_f16x3: cannot reserve %d B of LDS: %s", lds_bytes, hipGetErrorString(e));
+      }
+      lds_set = lds_bytes;
+    }
+    const dim3 grid((unsigned)G.mt, batch);
+    if (act == 1) hipLaunchKernelGGL(gemm_f16x3_as_kernel<1>, grid, dim3(512), lds_bytes, st, G);
+    else if (act == 2) hipLaunchKernelGGL(gemm_f16x3_as_kernel<2>, grid, dim3(512), lds_bytes, st, G);
+    else hipLaunchKernelGGL(gemm_f16x3_as_kernel<0>, grid, dim3(512), lds_bytes, st, G);
+    return check_launch("gemm_f16x3_as_kernel");
+  }
+  hipLaunchKernelGGL(gemm_f16x3_kernel, dim3((unsigned)blocks, batch), dim3(256), 0, st, G);
+  return check_launch("gemm_f16x3_kernel");
 }

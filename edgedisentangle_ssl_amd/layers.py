@@ -165,7 +165,8 @@ def _pack_score_operands(layers, x, x_all, att, H, Hp, f_in, f_out, fp):
     tops = [F.pad(l.W[:f_in], (0, fp - f_out)) for l in layers] + [x.new_zeros(f_in, fp)] * (Hp - H)
     bots = [F.pad(l.W[f_in:], (0, fp - f_out)) for l in layers] + [x.new_zeros(f_in, fp)] * (Hp - H)
     a_vec = torch.cat([F.pad(l.a[:, 0], (0, fp - f_out)) for l in layers] + [x.new_zeros(fp)] * (Hp - H))
-    return (ops_gemm.linear(x, torch.cat(tops, dim=1)), ops_gemm.linear(x_all, torch.cat(bots, dim=1)),
+    am = ops_gemm.amax_for(x_all)        # one max-|x| pass serves both GEMMs (x's rows are a subset of x_all's)
+    return (ops_gemm.linear(x, torch.cat(tops, dim=1), a_amax=am), ops_gemm.linear(x_all, torch.cat(bots, dim=1), a_amax=am),
             a_vec.contiguous())
 
 

@@ -1,11 +1,12 @@
-"""Dense contractions of the DISGAT path on the split-bf16 MFMA GEMM (csrc/gemm_split.hip).
+"""Dense contractions of the DISGAT path on the split-precision MFMA GEMMs (csrc/gemm_split.hip).
 
 `linear(a, w, ...)` computes act(a @ w + bias + init) for a 2-D `a`, or for a head-batched view
 `a` [H, M, K] with `w` [H, K, N] writing the concatenated-heads layout [M, H*N] (`init` is then
 [M, H*N], or [M, N] shared by every head).  Shapes outside
 the kernel's tiling (N % 128, K % 32) and DISGAT_GEMM=blas go to hipBLASLt through torch.matmul -
-still the GPU, still fp32.  DISGAT_GEMM=split3 selects the 3-product variant (not fp32-accurate;
-benchmark switch only).
+still the GPU, still fp32.  DISGAT_GEMM selects the scheme: `f16x3` (default: two fp16 planes per operand, 3
+products, operands accurate to 2^-23 per element), `split6` (three bf16 planes, 6 products, exact operands),
+`split3` (bf16, 3 products: not fp32-accurate, benchmark switch only), `blas`.
 """
 import os
 
@@ -18,7 +19,39 @@ ACT_NONE, ACT_ELU, ACT_LEAKY = 0, 1, 2
 
 
 def mode():
-    return os.environ.get("DISGAT_GEMM", "split6")
+    return os.environ.get("DISGAT_GEMM", "f16x3")
+
+
+def amax(a):
+    """Device scalar max |a| of a 2-D or head-batched 3-D operand (input of the f16x3 scheme's scale)."""
+    out = torch.zeros(1, dtype=torch.float32, device=a.device)
+    if a.dim() == 3:
+        hb, m, k = a.shape
+        _lib.call("disgat_amax", a.data_ptr(), a.stride(1), a.stride(0), m, k, hb, out.data_ptr(), ops._stream())
+    else:
+        m, k = a.shape
+        _lib.call("disgat_amax", a.data_ptr(), a.stride(0), 0, m, k, 1, out.data_ptr(), ops._stream())
+    return out
+
+
+def amax_for(a):
+    """amax(a) to share between several linear() calls on the same operand (or on row subsets of it: any upper
+    bound of max |a| is a valid scale input); None when the f16x3 kernel would not be used."""
+    if mode() != "f16x3" or not _kernel_ok(a, a.shape[-1], 128):
+        return None
+    return amax(a)
+
+
+def split_weight_f16(w):
+    """[..., K, N] fp32 -> (int16 view of fp16 planes [..., 2, N, K] = hi, lo of w^T * s, device scalar s).
+    s is the power of two that puts max |w| in [2^13, 2^14); lo carries an extra 2^11 (see gemm_f16x3_kernel)."""
+    wt = w.detach().transpose(-1, -2).contiguous()
+    mx = wt.abs().amax().clamp_min(1e-30)
+    s = torch.exp2(13.0 - torch.floor(torch.log2(mx))).reshape(1)
+    t = wt * s
+    hi = t.to(torch.float16)
+    lo = ((t - hi.float()) * 2048.0).to(torch.float16)
+    return torch.stack([hi, lo], dim=-3).contiguous().view(torch.int16), s
 
 
 def split_weight(w):
@@ -45,7 +78,7 @@ def _kernel_ok(a, k, n):
             and (a.dim() == 2 or a.stride(0) % 4 == 0))
 
 
-def _forward(a, w, bias, init, act, slope):
+def _forward(a, w, bias, init, act, slope, a_amax=None):
     batched = a.dim() == 3
     if batched:
         hb, m, k = a.shape
@@ -66,7 +99,6 @@ def _forward(a, w, bias, init, act, slope):
             out = out + (init.repeat(1, hb) if batched and init.shape == (m, n) and hb > 1 else init)
         return _apply_act(out, act, slope)
     out = torch.empty((m, hb * n), dtype=torch.float32, device=a.device)
-    planes = split_weight(w)
     init_bs = n if batched else 0
     if init is not None and batched and init.shape == (m, n) and init.stride(-1) == 1:
         init_bs = 0                                  # one [M,N] init shared by all heads: batch stride 0
@@ -74,6 +106,16 @@ def _forward(a, w, bias, init, act, slope):
         init = init.expand(m, hb * n).contiguous()
     if bias is not None:
         bias = bias.contiguous()
+    if mode() == "f16x3":
+        planes, b_scale = split_weight_f16(w)
+        if a_amax is None:
+            a_amax = amax(a)
+        _lib.call("disgat_gemm_f16x3", a.data_ptr(), a.stride(-2), a.stride(0) if batched else 0, planes.data_ptr(),
+                  a_amax.data_ptr(), b_scale.data_ptr(), ops._ptr(bias), ops._ptr(init),
+                  0 if init is None else init.stride(0), init_bs, out.data_ptr(), out.stride(0), n if batched else 0,
+                  m, n, k, hb, act, float(slope), ops._stream())
+        return out
+    planes = split_weight(w)
     _lib.call("disgat_gemm_split", a.data_ptr(), a.stride(-2), a.stride(0) if batched else 0, planes.data_ptr(),
               ops._ptr(bias), ops._ptr(init), 0 if init is None else init.stride(0), init_bs,
               out.data_ptr(), out.stride(0), n if batched else 0, m, n, k, hb, act, float(slope),
@@ -94,8 +136,8 @@ def _act_backward(g, out, act, slope):
 
 class _Linear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, a, w, bias, init, act, slope):
-        out = _forward(a, w, bias, init, act, slope)
+    def forward(ctx, a, w, bias, init, act, slope, a_amax=None):
+        out = _forward(a, w, bias, init, act, slope, a_amax)
         ctx.save_for_backward(a, w, out if act != ACT_NONE else None)
         ctx.meta = (act, slope, bias is not None, init is not None)
         ctx.init_shared = init is not None and a.dim() == 3 and init.shape[1] != out.shape[1]
@@ -127,9 +169,10 @@ class _Linear(torch.autograd.Function):
             gb = g.sum(0)
         if has_init and ctx.needs_input_grad[3]:
             gi = g.view(g.shape[0], a.shape[0], -1).sum(1) if ctx.init_shared else g
-        return ga, gw, gb, gi, None, None
+        return ga, gw, gb, gi, None, None, None
 
 
-def linear(a, w, bias=None, init=None, act=ACT_NONE, slope=0.01):
-    """act(a @ w + bias + init); see module docstring for the batched form (bias then is [H*N])."""
-    return _Linear.apply(a, w, bias, init, act, slope)
+def linear(a, w, bias=None, init=None, act=ACT_NONE, slope=0.01, a_amax=None):
+    """act(a @ w + bias + init); see module docstring for the batched form (bias then is [H*N]).
+    a_amax: optional precomputed amax(a) when the same operand feeds several GEMMs."""
+    return _Linear.apply(a, w, bias, init, act, slope, a_amax)

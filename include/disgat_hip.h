@@ -152,6 +152,22 @@ int disgat_gemm_split(const float* A, int64_t lda, int64_t a_batch_stride, const
                       int64_t ldc, int64_t c_batch_stride, int M, int N, int K, int batch, int act,
                       float slope, int terms, disgat_stream_t stream);
 
+/* The same contraction with two fp16 planes per operand and 3 partial products (half the matrix-core work):
+ * every element of A*s_A and B*s_B (s = power of two placing the operand's max magnitude in [2^13, 2^14)) is
+ * hi + lo*2^-11 with fp16 hi, lo, accurate to 2^-23 of the element; hi*hi, hi*lo, lo*hi are accumulated in fp32.
+ *   Bt_planes: [batch][2][N][K] fp16 = hi, lo of (B^T * s_B); b_scale: device float holding s_B;
+ *   a_amax: device float holding max |A| over the whole (batched) operand (disgat_amax); s_A is derived in-kernel.
+ * Other arguments as disgat_gemm_split. */
+int disgat_gemm_f16x3(const float* A, int64_t lda, int64_t a_batch_stride, const uint16_t* Bt_planes,
+                      const float* a_amax, const float* b_scale, const float* bias, const float* init,
+                      int64_t ldi, int64_t init_batch_stride, float* C, int64_t ldc, int64_t c_batch_stride,
+                      int M, int N, int K, int batch, int act, float slope, disgat_stream_t stream);
+
+/* *out = max(*out, max |A[b][m][k]|) over batch x M x K (K, lda, batch stride multiples of 4); the caller
+ * zeroes *out first. */
+int disgat_amax(const float* A, int64_t lda, int64_t a_batch_stride, int M, int K, int batch, float* out,
+                disgat_stream_t stream);
+
 /* Backward of the epilogue activation from the saved output (n contiguous floats, n % 4 == 0):
  * gin = g * (out > 0 ? 1 : (act == 1 ? out + 1 : slope)); act 1 = ELU, 2 = leaky ReLU.  gin may alias g. */
 int disgat_act_bwd(const float* g, const float* out, float* gin, int64_t n, int act, float slope,

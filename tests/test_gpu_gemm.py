@@ -1,4 +1,5 @@
-"""The split-bf16 MFMA GEMM against float64, with hipBLASLt's fp32 GEMM as the accuracy yardstick."""
+"""The split-precision MFMA GEMMs (f16x3: two fp16 planes, 3 products - the default; split6: three bf16 planes, 6
+products) against float64, with hipBLASLt's fp32 GEMM as the accuracy yardstick."""
 import numpy as np
 import pytest
 import torch
@@ -10,9 +11,15 @@ def _err(x, ref):
     return float((x.double() - ref).abs().max() / ref.abs().max())
 
 
+@pytest.fixture(params=["f16x3", "split6"])
+def scheme(request, monkeypatch):
+    monkeypatch.setenv("DISGAT_GEMM", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("m,k,n", [(1000, 256, 256), (4096, 64, 512), (777, 2048, 256), (130, 32, 128),
                                    (70001, 256, 256), (33000, 96, 2048)])
-def test_plain_accuracy_matches_fp32_gemm(m, k, n):
+def test_plain_accuracy_matches_fp32_gemm(m, k, n, scheme):
     from edgedisentangle_ssl_amd import ops_gemm
     g = torch.Generator(device="cuda").manual_seed(1)
     a = torch.randn(m, k, device="cuda", generator=g) * torch.exp(torch.randn(m, 1, device="cuda", generator=g))
@@ -22,6 +29,35 @@ def test_plain_accuracy_matches_fp32_gemm(m, k, n):
     blas = a @ w
     e_got, e_blas = _err(got, ref), _err(blas, ref)
     assert e_got <= max(2.0 * e_blas, 3e-7), (e_got, e_blas)
+
+
+def test_wide_dynamic_range_keeps_per_element_precision(scheme):
+    """One global power-of-two scale per operand (f16x3): an outlier 2^12 times the typical magnitude and rows 2^-10
+    below it (2^-22 of the maximum; the scheme keeps full per-element precision down to 2^-27 of it) must not cost
+    the ordinary elements their precision - every row is checked against its own magnitude."""
+    from edgedisentangle_ssl_amd import ops_gemm
+    g = torch.Generator(device="cuda").manual_seed(7)
+    m, k, n = 3000, 256, 256
+    a = torch.randn(m, k, device="cuda", generator=g)
+    a[5, 17] = 2.0 ** 12
+    a[1000:1100] *= 2.0 ** -10
+    w = torch.randn(k, n, device="cuda", generator=g) * 0.1
+    w[3, 9] = 300.0
+    ref = a.double() @ w.double()
+    row_scale = (a.double().abs() @ w.double().abs()).clamp_min(1e-300)       # sum_k |a||w|: the natural error scale
+    e_got = float(((ops_gemm.linear(a, w).double() - ref).abs() / row_scale).max())
+    e_blas = float((((a @ w).double() - ref).abs() / row_scale).max())
+    assert e_got <= max(2.0 * e_blas, 2e-7), (e_got, e_blas)
+
+
+def test_zero_and_tiny_operands(scheme):
+    from edgedisentangle_ssl_amd import ops_gemm
+    a = torch.zeros(300, 64, device="cuda")
+    w = torch.randn(64, 128, device="cuda")
+    assert torch.equal(ops_gemm.linear(a, w), torch.zeros(300, 128, device="cuda"))
+    a = torch.randn(300, 64, device="cuda") * 1e-25
+    ref = a.double() @ w.double()
+    assert _err(ops_gemm.linear(a, w), ref) < 1e-6
 
 
 def test_batched_heads_bias_init_activation_and_grads():

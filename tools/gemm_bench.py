@@ -28,9 +28,18 @@ for name, ashape, wshape, hb in cases:
         flops = 2.0 * ashape[0] * ashape[1] * wshape[1]
         blas = lambda: a @ w
     res = {}
-    for md in ("blas", "split6"):
-        os.environ["DISGAT_GEMM"] = md
-        fn = blas if md == "blas" else (lambda: ops_gemm._forward(a, w, None, None, 0, 0.0))
+    ref = None
+    for md in ("blas", "split6", "f16x3", "f16x3+amax"):
+        os.environ["DISGAT_GEMM"] = md.split("+")[0]
+        am = ops_gemm.amax(a) if md == "f16x3" else None          # "f16x3": amax precomputed; "+amax": pass included
+        fn = blas if md == "blas" else (lambda: ops_gemm._forward(a, w, None, None, 0, 0.0, am))
         ms = timeit(fn, 5)
         res[md] = (ms, flops / ms / 1e9)
-    print(f"{name:48s} " + "  ".join(f"{k}: {v[0]:7.3f} ms {v[1]:6.1f} TF" for k, v in res.items()))
+        if M <= 200_000:                                           # error vs fp64 on small runs
+            out = fn()
+            out = out if not hb else out.view(M, hb, -1).permute(1, 0, 2) if md != "blas" else out
+            if ref is None:
+                ref = (a.double() @ w.double()) if not hb else torch.bmm(a.double(), w.double())
+            res[md] += (float((out.double() - ref).abs().max() / ref.abs().max()),)
+    print(f"{name:44s} " + "  ".join(f"{k}: {v[0]:6.3f} ms {v[1]:5.1f} TF" + (f" err {v[2]:.1e}" if len(v) > 2 else "")
+                                       for k, v in res.items()))
