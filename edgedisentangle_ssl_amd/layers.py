@@ -115,8 +115,10 @@ class DisGALayer(nn.Module):
 class HeadList(list):
     """List of the H per-head outputs [N,F_out] (what the reference's fusers receive,
     models.py:230-233).  All heads are column slices of ONE buffer `fused` [N, H*F_out], which a
-    fuser may use directly instead of re-concatenating (FuseLayer below does)."""
+    fuser may use directly instead of re-concatenating (FuseLayer below does); `fused_amax` is an upper
+    bound of max |fused| (device scalar) for the GEMMs that consume it."""
     fused = None
+    fused_amax = None
     pre_elu = None
 
 
@@ -141,7 +143,7 @@ def _kernel_heads(att, Hp, f_out, f_in_p=0):
     raise NotImplementedError(f"att=3 kernel envelope: a single head wider than 1024 features (nhid={f_out})")
 
 
-def _pack_score_operands(layers, x, x_all, att, H, Hp, f_in, f_out, fp):
+def _pack_score_operands(layers, x, x_all, att, H, Hp, f_in, f_out, fp, am=None):
     """Dense, differentiable (torch ops -> MFMA GEMMs) preparation of the per-node score operands.
     x: the rows this process owns; x_all: every node a column index can name (== x unsharded).
 
@@ -150,7 +152,8 @@ def _pack_score_operands(layers, x, x_all, att, H, Hp, f_in, f_out, fp):
     att 2 (layers.py:362-365):  e = <x_r W, x_c W> = <x_r (W W^T), x_c>           -> P = x (W W^T)
     att 3 (layers.py:374-379):  e = a . lrelu([x_r || x_c] W) = a . lrelu(P[r] + Q[c]),
                                 P = x W[:F_in], Q = x W[F_in:]                     -> [N,Hp*fp] each
-    Returns (rowop, colop, a_vec); fp = padded per-head width of the att-3 operands.
+    Returns (rowop, colop, a_vec); fp = padded per-head width of the att-3 operands.  am: max |x_all| as a device
+    scalar (or None), the scale input of the f16x3 GEMMs (x's rows are a subset of x_all's, so it serves both).
     """
     if att == 1:
         zero = [x.new_zeros(f_in)] * (Hp - H)
@@ -161,11 +164,10 @@ def _pack_score_operands(layers, x, x_all, att, H, Hp, f_in, f_out, fp):
         f_in_p = (f_in + 3) // 4 * 4
         ms = [F.pad(l.W @ l.W.t(), (0, f_in_p - f_in)) for l in layers]
         ms += [x.new_zeros(f_in, f_in_p)] * (Hp - H)
-        return ops_gemm.linear(x, torch.cat(ms, dim=1)), None, None                 # [N, Hp*F_in_p]
+        return ops_gemm.linear(x, torch.cat(ms, dim=1), a_amax=am), None, None      # [N, Hp*F_in_p]
     tops = [F.pad(l.W[:f_in], (0, fp - f_out)) for l in layers] + [x.new_zeros(f_in, fp)] * (Hp - H)
     bots = [F.pad(l.W[f_in:], (0, fp - f_out)) for l in layers] + [x.new_zeros(f_in, fp)] * (Hp - H)
     a_vec = torch.cat([F.pad(l.a[:, 0], (0, fp - f_out)) for l in layers] + [x.new_zeros(fp)] * (Hp - H))
-    am = ops_gemm.amax_for(x_all)        # one max-|x| pass serves both GEMMs (x's rows are a subset of x_all's)
     return (ops_gemm.linear(x, torch.cat(tops, dim=1), a_amax=am), ops_gemm.linear(x_all, torch.cat(bots, dim=1), a_amax=am),
             a_vec.contiguous())
 
@@ -210,7 +212,14 @@ def disga_heads(layers, x, adj, aux_indices=None, head_ranges=None, aux_only=Fal
     x_all = parallel.all_gather_rows(x, graph)       # sharded: one exchange per layer
     xg = x_all if (f_in_p == f_in and x_all.is_contiguous()) else F.pad(x_all, (0, f_in_p - f_in)).contiguous()
 
-    rowop, colop, a_vec = _pack_score_operands(layers, x, x_all, att, H, Hp, f_in, f_out, fp)
+    # Scale inputs of the f16x3 GEMMs.  max |x| is measured once (1 pass over the layer input); the two 8x larger
+    # operands get analytic upper bounds instead of their own pass: every Z row is a non-negative combination of x
+    # rows with total weight <= 1/(1-p) (softmax weights, attention dropout rescaling; SageConv only divides further),
+    # and a GEMM output is bounded by its input bound times the weight's largest column abs-sum.  A loose bound costs
+    # no precision (the scheme is exact to 2^-23 per element down to 2^-27 of the scale), only range.
+    am_x = ops_gemm.amax_for(x_all)
+    z_bound = None if am_x is None else am_x * (1.001 / (1.0 - drop[0]))
+    rowop, colop, a_vec = _pack_score_operands(layers, x, x_all, att, H, Hp, f_in, f_out, fp, am_x)
     # per-head operand width inside a row of rowop / colop (att 1: one scalar, att 2: F_in_p, att 3: fp)
     w_row = {1: 1, 2: f_in_p, 3: fp}[att]
 
@@ -253,18 +262,24 @@ def disga_heads(layers, x, adj, aux_indices=None, head_ranges=None, aux_only=Fal
         act_code = ops_gemm.ACT_ELU if concat else ops_gemm.ACT_NONE         # ELU fused in the GEMM epilogue
         if gnn == "AT":                                                      # layers.py:397-399
             w = torch.stack([l.W_em for l in layers])                        # [H,F_in,F_out]
-            fused = ops_gemm.linear(zt, w, None, None, act_code)
+            fused = ops_gemm.linear(zt, w, None, None, act_code, a_amax=z_bound)
+            pre_bound = None if z_bound is None else z_bound * w.detach().abs().sum(1).max()
         elif gnn == "SAGE":                                                  # layers.py:96-110
             wx = torch.cat([l.ag_layer.proj.weight[:, :f_in].t() for l in layers], dim=1)   # [F_in, H*F_out]
             wn = torch.stack([l.ag_layer.proj.weight[:, f_in:].t() for l in layers])        # [H,F_in,F_out]
-            fused = ops_gemm.linear(zt, wn, None, ops_gemm.linear(x, wx), act_code)
+            fused = ops_gemm.linear(zt, wn, None, ops_gemm.linear(x, wx, a_amax=am_x), act_code, a_amax=z_bound)
+            pre_bound = None if z_bound is None else (z_bound * wn.detach().abs().sum(1).max()
+                                                      + am_x * wx.detach().abs().sum(0).max())
         else:                                                                # layers.py:38-54
             w = torch.stack([l.ag_layer.weight for l in layers])
             b = torch.cat([l.ag_layer.bias for l in layers])                 # [H*F_out]
-            fused = ops_gemm.linear(zt, w, b, None, act_code)
+            fused = ops_gemm.linear(zt, w, b, None, act_code, a_amax=z_bound)
+            pre_bound = None if z_bound is None else z_bound * w.detach().abs().sum(1).max() + b.detach().abs().max()
         act = fused if concat else F.elu(fused)                              # layers.py:508-509
         heads = HeadList(act[:, h * f_out:(h + 1) * f_out] for h in range(H))
         heads.fused = act
+        # |elu(v)| <= max(|v|, 1)
+        heads.fused_amax = None if pre_bound is None else torch.clamp(pre_bound * 1.001, min=1.0).reshape(1)
         heads.pre_elu = None if concat else [fused[:, h * f_out:(h + 1) * f_out] for h in range(H)]
 
         e_list = [edge_e[h].unsqueeze(1) for h in range(H)]
@@ -320,7 +335,8 @@ class FuseLayer(nn.Module):
                 features = torch.cat([features, residue], dim=-1)
             if features.is_cuda and features.dim() == 2:     # Linear (+ leaky_relu) in one MFMA GEMM with fused epilogue
                 act = ops_gemm.ACT_NONE if self.args.fuse_no_relu else ops_gemm.ACT_LEAKY
-                return ops_gemm.linear(features, self.fuse.weight.t(), self.fuse.bias, None, act, 0.01)
+                am = None if use_res else getattr(feature_list, "fused_amax", None)
+                return ops_gemm.linear(features, self.fuse.weight.t(), self.fuse.bias, None, act, 0.01, a_amax=am)
             feature = self.fuse(features)
         elif self.args.residue_type == 1:
             if use_res:

@@ -239,7 +239,7 @@ class DifHeadTrainer(Trainer):
                 shared = ops_gemm.linear(inp, lin.weight[:, :f_in].t(), lin.bias)
                 w_h = lin.weight[:, f_in:].t().unsqueeze(0).expand(nh, fo, -1)
                 t = ops_gemm.linear(fused.view(-1, nh, fo).permute(1, 0, 2), w_h, None, shared, ops_gemm.ACT_LEAKY,
-                                    mods[1].negative_slope)                     # [N, H*hidden]
+                                    mods[1].negative_slope, a_amax=getattr(heads, "fused_amax", None))   # [N, H*hidden]
                 t = t.view(t.shape[0] * nh, -1)
                 for m in mods[2:]:
                     t = m(t)

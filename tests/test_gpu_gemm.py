@@ -110,3 +110,40 @@ def test_fallback_shapes_use_blas():
     w = torch.randn(16, 24, device="cuda")
     assert torch.allclose(ops_gemm.linear(a, w, act=ops_gemm.ACT_LEAKY, slope=0.01),
                           torch.nn.functional.leaky_relu(a @ w), atol=1e-5)
+
+
+@pytest.mark.parametrize("gnn", ["AT", "SAGE", "GCN"])
+@pytest.mark.parametrize("train", [False, True])
+def test_analytic_operand_bounds_hold(gnn, train):
+    """disga_heads hands the f16x3 GEMMs analytic upper bounds of max |Z| and max |fused| instead of measuring the two
+    largest operands; a bound below the true maximum would overflow fp16."""
+    import inputs_common as ic
+    import edgedisentangle_ssl_amd as pkg
+    from edgedisentangle_ssl_amd import ops_gemm
+    dev = torch.device("cuda")
+    idx, vals, n = ic.tiny_graph()
+    adj = torch.sparse_coo_tensor(idx, vals, (n, n)).to(dev)
+    x = (ic.features(5, n, 64) * 30.0).to(dev)
+    layers = [ic.load_params(pkg.DisGALayer(64, 128, dropout=0.5, alpha=0.1, att_type=3, gnn_type=gnn), 40 + h).to(dev)
+              for h in range(4)]
+    for lay in layers:
+        lay.train(train)
+    seen = []
+    real = ops_gemm._forward
+
+    def spy(a, w, bias, init, act, slope, a_amax=None):
+        if a_amax is not None:
+            seen.append((float(a.abs().max()), float(a_amax)))
+        return real(a, w, bias, init, act, slope, a_amax)
+
+    ops_gemm._forward = spy
+    try:
+        torch.manual_seed(0)
+        heads, _, _ = pkg.disga_heads(layers, x, adj)
+    finally:
+        ops_gemm._forward = real
+    assert len(seen) >= 3
+    for true_max, bound in seen:
+        assert bound >= true_max, (true_max, bound)
+    assert float(heads.fused_amax) >= float(heads.fused.abs().max())
+    assert torch.isfinite(heads.fused).all()

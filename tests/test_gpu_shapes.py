@@ -44,12 +44,26 @@ def test_layer_shapes_forward_backward(dev, H, f_in, f_out, att, gnn, monkeypatc
     idx, n = small_graph()
     ci = ic.coalesced_index_set(idx, n)
     adj = torch.sparse_coo_tensor(idx, torch.ones(idx.shape[1]), (n, n)).to(dev)
-    x = (ic.features(3, n, f_in) * 0.5)
     aux = [ic.aux_pairs(8, n, 333, "s0"), ic.aux_pairs(9, n, 97, "s1")]
     lo1, hi1 = (0, max(1, H // 2))
     ranges = [None, (lo1, hi1)]
     layers = [ic.load_params(pkg.DisGALayer(f_in, f_out, dropout=0.0, alpha=0.1, att_type=att, gnn_type=gnn), 500 + h).to(dev).eval()
               for h in range(H)]
+    # att 3: leaky_relu's kink at z = P[r] + Q[c] = 0.  An fp32 evaluation within rounding (~1e-7) of it may land on
+    # the other side than the float64 oracle and flip one gradient term between 0.01 and 1 - a property of the
+    # function, not of the kernels - so the input is redrawn until no argument sits that close (tools/fuzz_parity.py).
+    for seed in range(3, 23):
+        x = (ic.features(seed, n, f_in) * 0.5)
+        near = 0
+        if att == 3:
+            for lay in layers:
+                w = lay.W.detach().cpu().double()
+                for r_, c_ in [(ci[0], ci[1])] + [(a_[0], a_[1]) for a_ in aux]:
+                    near += int(((x.double()[r_] @ w[:f_in] + x.double()[c_] @ w[f_in:]).abs() < 5e-6).sum())
+        if near == 0:
+            break
+    else:
+        pytest.skip("could not draw an input away from the leaky-ReLU kink")
     xg = x.to(dev).requires_grad_(True)
     heads, e_list, aux_out = pkg.disga_heads(layers, xg, adj, [a.to(dev) for a in aux], ranges)
 
