@@ -537,6 +537,8 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x3_as_kernel(const GemmHArgs G
   for (int ns = 0; ns * 256 < G.N; ++ns) {
     const int n_w = ns * 256 + wave * 32;
     if (n_w >= G.N) break;                                          // N % 256 == 128: waves 4-7 idle in the last step
+    // bias and the additive init matrix seed the hi*hi accumulator (times s_A s_B, a power of two: exact) instead
+    // of being added per element in the epilogue, where 64 dependent loads per lane sat between the stores
     f32x4v acc[8][2], acx[8][2];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -545,6 +547,22 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x3_as_kernel(const GemmHArgs G
         acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
         acx[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
       }
+    if (bias || init) {
+      const float seed = sA * *G.b_scale;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int cj = n_w + 16 * j + (lane & 15);
+        const float bj = bias ? bias[cj] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = m0 + 16 * i + 4 * (lane >> 4) + r;
+            const float iv = (init && row < G.M) ? init[(int64_t)row * G.ldi + cj] : 0.f;
+            acc[i][j][r] = (bj + iv) * seed;
+          }
+      }
+    }
     const uint16_t* bp = Bt + (int64_t)n_w * K + b_off;
     f16x8 bh_n[2], bl_n[2];
 #pragma unroll
@@ -590,36 +608,33 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x3_as_kernel(const GemmHArgs G
     }
     // ---- epilogue: C/D layout col = lane & 15, row = 4*(lane >> 4) + r.  Swapping the upper half of tile j=0
     // with the lower half of tile j=1 leaves every register with 2 rows x 32 columns: full 128-B stores.
-    // Addresses: one per-lane pointer per N-step plus a uniform row offset (one 64-bit add per store; the row
-    // strides are made opaque per step, otherwise the 64 loop-invariant row offsets are hoisted out of the N loop and
-    // spilled); the activation is a template parameter (a run-time switch computed every branch for every element);
-    // ragged last tiles take the checked copy of the loop.  Before these changes the epilogue's ~16 VALU ops per
-    // element outweighed the MFMAs of the whole N-step.
+    // Epilogue cost matters here: per N-step a wave retires 384 MFMAs and 128 outputs per lane.  Addresses are two
+    // per-lane pointers (rows +0 and +8 of each 16-row tile) advanced by the uniform row stride - one 64-bit add per
+    // store, no multiplies; the activation is a template parameter (a run-time switch evaluated every branch for every
+    // element); ragged last tiles take the checked copy of the loop.
     const int col = n_w + ocol;
-    const float bv = bias ? bias[col] : 0.f;
-    int64_t ldc = G.ldc, ldi = G.ldi;
-    asm volatile("" : "+s"(ldc), "+s"(ldi));
-    float* cp = C + (int64_t)(m0 + orow) * ldc + col;
-    const float* ip = init ? init + (int64_t)(m0 + orow) * ldi + col : nullptr;
     const bool full = m0 + AS_BM <= G.M;
+    int64_t ldc = G.ldc;
+    asm volatile("" : "+s"(ldc));
+    float* p0 = C + (int64_t)(m0 + orow) * ldc + col;
+    float* p1 = p0 + 8 * ldc;
     auto emit = [&](auto checked) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
+      for (int i = 0; i < 8; ++i) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float v0 = fmaf(acx[i][0][r], xw, acc[i][0][r] * inv);
           const float v1 = fmaf(acx[i][1][r], xw, acc[i][1][r] * inv);
           const auto sw2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v0), __float_as_uint(v1), false, false);
-#pragma unroll
-          for (int s2 = 0; s2 < 2; ++s2) {
-            const int dr = 16 * i + 8 * s2 + r;
-            if (!decltype(checked)::value || m0 + dr + orow < G.M) {
-              float v = __uint_as_float(sw2[s2]) + bv;
-              if (init) v += ip[dr * ldi];                                     // uniform test
-              cp[dr * ldc] = act_ct<ACT>(v, G.slope);
-            }
-          }
+          const int row = m0 + orow + 16 * i + r;
+          if (!decltype(checked)::value || row < G.M) *p0 = act_ct<ACT>(__uint_as_float(sw2[0]), G.slope);
+          if (!decltype(checked)::value || row + 8 < G.M) *p1 = act_ct<ACT>(__uint_as_float(sw2[1]), G.slope);
+          p0 += ldc;
+          p1 += ldc;
         }
+        p0 += 12 * ldc;
+        p1 += 12 * ldc;
+      }
     };
     if (full) emit(std::false_type{});
     else emit(std::true_type{});
