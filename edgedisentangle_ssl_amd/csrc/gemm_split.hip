@@ -475,6 +475,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(const GemmHArgs G) {
 // from LDS and B fragments straight from global memory (the weight planes are L2-resident, k contiguous = the
 // MFMA B layout; one k-step prefetched), and stores its results directly - after one v_permlane32_swap per register
 // pair every store instruction writes two full 128-B rows.  No barrier after the A tile is in place.
+// What still bounds it (ablations at [1e6,256] x [256,2048], 3.8 ms): the 8 GB of results leave each CU at its share
+// of the HBM write rate (~21 GB/s): a wave's 64 stores per N-step block in the issue queue, and the other wave's B
+// fragment loads queue behind them in the same vector-memory path (no epilogue: -1.5 ms; no B reloads: -1.0 ms).
+// Tried without gain: issuing all LDS fragment reads ahead of the MFMAs (the two waves per SIMD already hide that
+// latency) and a per-SIMD token that forces the two waves into anti-phase (MFMA loop vs stores).  The next step is
+// to retire the previous N-step's results a few stores per k-step inside the next MFMA loop (needs a second
+// accumulator set, i.e. a 64 x 32 wave tile).
 constexpr int AS_BM = 128, AS_PAD = 8;     // LDS row = K + 8 fp16: row stride = 4 banks mod 64 -> conflict-free b128 reads
 
 template <int ACT>
@@ -585,29 +592,43 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x3_as_kernel(const GemmHArgs G
         }
       }
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {          // 4 row tiles at a time: 16 + 4 fragment registers live
-        f16x8 ah[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          ah[i] = *reinterpret_cast<const f16x8*>(&lds_as[a_off + (half * 4 + i) * 16 * KP + t * GBK]);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
+      for (int half = 0; half < 2; ++half) {          // 4 row tiles at a time
+        // Hand-ordered (sched_barriers pin it): left to itself the compiler sinks every ds_read next to its first
+        // use and waits for it with nothing else in flight.  The lo fragments are fetched while the hi MFMAs run.
+        auto lda = [&](int pl, int i) {
+          return *reinterpret_cast<const f16x8*>(&lds_as[pl * plane + a_off + (half * 4 + i) * 16 * KP + t * GBK]);
+        };
+        auto hi2 = [&](const f16x8& a, int i) {
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
-            acc[half * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc[half * 4 + i][j], 0, 0, 0);
-            acx[half * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acx[half * 4 + i][j], 0, 0, 0);
+            acc[half * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bh[j], acc[half * 4 + i][j], 0, 0, 0);
+            acx[half * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bl[j], acx[half * 4 + i][j], 0, 0, 0);
           }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const f16x8 al = *reinterpret_cast<const f16x8*>(&lds_as[plane + a_off + (half * 4 + i) * 16 * KP + t * GBK]);
+        };
+        auto lo2 = [&](const f16x8& a, int i) {
 #pragma unroll
           for (int j = 0; j < 2; ++j)
-            acx[half * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[j], acx[half * 4 + i][j], 0, 0, 0);
-        }
+            acx[half * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bh[j], acx[half * 4 + i][j], 0, 0, 0);
+        };
+        const f16x8 ah0 = lda(0, 0), ah1 = lda(0, 1), ah2 = lda(0, 2), ah3 = lda(0, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        hi2(ah0, 0);
+        hi2(ah1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const f16x8 al0 = lda(1, 0), al1 = lda(1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        hi2(ah2, 2);
+        hi2(ah3, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        const f16x8 al2 = lda(1, 2), al3 = lda(1, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        lo2(al0, 0);
+        lo2(al1, 1);
+        lo2(al2, 2);
+        lo2(al3, 3);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
-    // ---- epilogue: C/D layout col = lane & 15, row = 4*(lane >> 4) + r.  Swapping the upper half of tile j=0
-    // with the lower half of tile j=1 leaves every register with 2 rows x 32 columns: full 128-B stores.
     // Epilogue cost matters here: per N-step a wave retires 384 MFMAs and 128 outputs per lane.  Addresses are two
     // per-lane pointers (rows +0 and +8 of each 16-row tile) advanced by the uniform row stride - one 64-bit add per
     // store, no multiplies; the activation is a template parameter (a run-time switch evaluated every branch for every
