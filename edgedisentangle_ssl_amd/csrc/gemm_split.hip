@@ -662,6 +662,39 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x3_as_kernel(const GemmHArgs G
   }
 }
 
+// Weight preparation for the f16x3 scheme in two small launches (the torch formulation took ~15): max |W| over an
+// arbitrarily strided [batch][K][N] weight, then hi / lo planes of (W^T * s) as [batch][2][N][K] fp16 and s itself.
+__global__ __launch_bounds__(256) void wamax_kernel(const float* __restrict__ W, int64_t sb, int64_t sk, int64_t sn, int K,
+                                                    int N, int64_t total, uint32_t* __restrict__ out) {
+  uint32_t m = 0u;
+  const int64_t kn = (int64_t)K * N;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t b = i / kn, r = i - b * kn;
+    const int64_t k = r / N, n = r - k * N;
+    m = max(m, __float_as_uint(fabsf(W[b * sb + k * sk + n * sn])));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+  if ((threadIdx.x & 63) == 0 && m != 0u) atomicMax(out, m);
+}
+
+__global__ __launch_bounds__(256) void wsplit_kernel(const float* __restrict__ W, int64_t sb, int64_t sk, int64_t sn, int K,
+                                                     int N, int64_t total, const float* __restrict__ amax,
+                                                     uint16_t* __restrict__ planes, float* __restrict__ scale_out) {
+  const float s = f16_scale(*amax);
+  if (blockIdx.x == 0 && threadIdx.x == 0) *scale_out = s;
+  const int64_t kn = (int64_t)K * N;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t b = i / kn, r = i - b * kn;
+    const int64_t n = r / K, k = r - n * K;                       // output order [n][k]: coalesced plane writes
+    const float t = W[b * sb + k * sk + n * sn] * s;
+    const _Float16 h = (_Float16)t;
+    const _Float16 l = (_Float16)((t - (float)h) * 2048.f);
+    planes[(b * 2 + 0) * kn + r] = *reinterpret_cast<const uint16_t*>(&h);
+    planes[(b * 2 + 1) * kn + r] = *reinterpret_cast<const uint16_t*>(&l);
+  }
+}
+
 // max |A| over a (batched, strided) fp32 operand into *out (a device float the caller zeroed): the bit pattern
 // of a non-negative float orders like an unsigned integer, so the reduction is one atomicMax per wave.
 __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ A, int64_t lda, int64_t a_bs, int64_t rows,
@@ -739,9 +772,30 @@ extern "C" int disgat_gemm_split(const float* A, int64_t lda, int64_t a_batch_st
   return check_launch("gemm_split_kernel");
 }
 
+extern "C" int disgat_split_f16(const float* W, int64_t stride_b, int64_t stride_k, int64_t stride_n, int K, int N, int batch,
+                                uint16_t* planes, float* amax_scale, disgat_stream_t stream) {
+  using namespace disgat;
+  DISGAT_REQUIRE(W && planes && amax_scale && K > 0 && N > 0 && batch > 0, "split_f16: null pointer / bad sizes");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const hipError_t e = hipMemsetAsync(amax_scale, 0, 2 * sizeof(float), st);
+  if (e != hipSuccess) return fail((int)e, "split_f16: memset failed: %s", hipGetErrorString(e));
+  const int64_t total = (int64_t)batch * K * N;
+  const int grid = (int)(total / 256 + 1 < 1024 ? total / 256 + 1 : 1024);
+  hipLaunchKernelGGL(wamax_kernel, dim3(grid), dim3(256), 0, st, W, stride_b, stride_k, stride_n, K, N, total,
+                     reinterpret_cast<uint32_t*>(amax_scale));
+  hipLaunchKernelGGL(wsplit_kernel, dim3(grid), dim3(256), 0, st, W, stride_b, stride_k, stride_n, K, N, total, amax_scale,
+                     planes, amax_scale + 1);
+  return check_launch("wsplit_kernel");
+}
+
 extern "C" int disgat_amax(const float* A, int64_t lda, int64_t a_batch_stride, int M, int K, int batch, float* out,
                            disgat_stream_t stream) {
   using namespace disgat;
+  DISGAT_REQUIRE(out != nullptr, "amax: null output");
+  {
+    const hipError_t e = hipMemsetAsync(out, 0, sizeof(float), reinterpret_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail((int)e, "amax: memset failed: %s", hipGetErrorString(e));
+  }
   if (M == 0 || batch == 0 || K == 0) return 0;
   DISGAT_REQUIRE(A && out && M > 0 && K > 0 && batch > 0, "amax: null pointer / bad sizes");
   DISGAT_REQUIRE(K % 4 == 0 && lda % 4 == 0 && a_batch_stride % 4 == 0 && aligned16(A), "amax: K, lda and the batch stride must be multiples of 4, A 16-byte aligned");

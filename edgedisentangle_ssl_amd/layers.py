@@ -143,6 +143,23 @@ def _kernel_heads(att, Hp, f_out, f_in_p=0):
     raise NotImplementedError(f"att=3 kernel envelope: a single head wider than 1024 features (nhid={f_out})")
 
 
+def _memo(layers, tag, build):
+    """Per-layer cache of packed weights (and their GEMM split planes, norms) for forwards that record no autograd
+    graph: inference repeats the same ~40 small packing kernels per layer otherwise, which is most of a small graph's
+    latency.  Keyed on every parameter's identity, storage and version, so any update rebuilds; one entry per tag."""
+    params = [p for l in layers for p in l.parameters()]
+    if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+        return build()
+    key = tuple((id(p), p.data_ptr(), p._version) for p in params)
+    cache = layers[0].__dict__.setdefault("_disgat_memo", {})
+    hit = cache.get(tag)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    val = build()
+    cache[tag] = (key, val)
+    return val
+
+
 def _pack_score_operands(layers, x, x_all, att, H, Hp, f_in, f_out, fp, am=None):
     """Dense, differentiable (torch ops -> MFMA GEMMs) preparation of the per-node score operands.
     x: the rows this process owns; x_all: every node a column index can name (== x unsharded).
@@ -165,11 +182,15 @@ def _pack_score_operands(layers, x, x_all, att, H, Hp, f_in, f_out, fp, am=None)
         ms = [F.pad(l.W @ l.W.t(), (0, f_in_p - f_in)) for l in layers]
         ms += [x.new_zeros(f_in, f_in_p)] * (Hp - H)
         return ops_gemm.linear(x, torch.cat(ms, dim=1), a_amax=am), None, None      # [N, Hp*F_in_p]
-    tops = [F.pad(l.W[:f_in], (0, fp - f_out)) for l in layers] + [x.new_zeros(f_in, fp)] * (Hp - H)
-    bots = [F.pad(l.W[f_in:], (0, fp - f_out)) for l in layers] + [x.new_zeros(f_in, fp)] * (Hp - H)
-    a_vec = torch.cat([F.pad(l.a[:, 0], (0, fp - f_out)) for l in layers] + [x.new_zeros(fp)] * (Hp - H))
-    return (ops_gemm.linear(x, torch.cat(tops, dim=1), a_amax=am), ops_gemm.linear(x_all, torch.cat(bots, dim=1), a_amax=am),
-            a_vec.contiguous())
+    def pack3():
+        tops = [F.pad(l.W[:f_in], (0, fp - f_out)) for l in layers] + [x.new_zeros(f_in, fp)] * (Hp - H)
+        bots = [F.pad(l.W[f_in:], (0, fp - f_out)) for l in layers] + [x.new_zeros(f_in, fp)] * (Hp - H)
+        a_vec = torch.cat([F.pad(l.a[:, 0], (0, fp - f_out)) for l in layers] + [x.new_zeros(fp)] * (Hp - H))
+        wt, wb = torch.cat(tops, dim=1), torch.cat(bots, dim=1)
+        return wt, wb, a_vec.contiguous(), ops_gemm.presplit(wt), ops_gemm.presplit(wb)
+
+    wt, wb, a_vec, st, sb = _memo(layers, ("att3", fp, Hp), pack3)
+    return ops_gemm.linear(x, wt, a_amax=am, w_split=st), ops_gemm.linear(x_all, wb, a_amax=am, w_split=sb), a_vec
 
 
 def disga_heads(layers, x, adj, aux_indices=None, head_ranges=None, aux_only=False):
@@ -261,9 +282,13 @@ def disga_heads(layers, x, adj, aux_indices=None, head_ranges=None, aux_only=Fal
         concat = all(l.concat for l in layers)
         act_code = ops_gemm.ACT_ELU if concat else ops_gemm.ACT_NONE         # ELU fused in the GEMM epilogue
         if gnn == "AT":                                                      # layers.py:397-399
-            w = torch.stack([l.W_em for l in layers])                        # [H,F_in,F_out]
-            fused = ops_gemm.linear(zt, w, None, None, act_code, a_amax=z_bound)
-            pre_bound = None if z_bound is None else z_bound * w.detach().abs().sum(1).max()
+            def pack_at():
+                w = torch.stack([l.W_em for l in layers])                    # [H,F_in,F_out]
+                return w, ops_gemm.presplit(w), w.detach().abs().sum(1).max()
+
+            w, ws, wnorm = _memo(layers, "proj_AT", pack_at)
+            fused = ops_gemm.linear(zt, w, None, None, act_code, a_amax=z_bound, w_split=ws)
+            pre_bound = None if z_bound is None else z_bound * wnorm
         elif gnn == "SAGE":                                                  # layers.py:96-110
             wx = torch.cat([l.ag_layer.proj.weight[:, :f_in].t() for l in layers], dim=1)   # [F_in, H*F_out]
             wn = torch.stack([l.ag_layer.proj.weight[:, f_in:].t() for l in layers])        # [H,F_in,F_out]
@@ -336,7 +361,8 @@ class FuseLayer(nn.Module):
             if features.is_cuda and features.dim() == 2:     # Linear (+ leaky_relu) in one MFMA GEMM with fused epilogue
                 act = ops_gemm.ACT_NONE if self.args.fuse_no_relu else ops_gemm.ACT_LEAKY
                 am = None if use_res else getattr(feature_list, "fused_amax", None)
-                return ops_gemm.linear(features, self.fuse.weight.t(), self.fuse.bias, None, act, 0.01, a_amax=am)
+                ws = _memo([self], "fuse", lambda: ops_gemm.presplit(self.fuse.weight.t()))
+                return ops_gemm.linear(features, self.fuse.weight.t(), self.fuse.bias, None, act, 0.01, a_amax=am, w_split=ws)
             feature = self.fuse(features)
         elif self.args.residue_type == 1:
             if use_res:

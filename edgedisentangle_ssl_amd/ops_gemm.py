@@ -24,7 +24,7 @@ def mode():
 
 def amax(a):
     """Device scalar max |a| of a 2-D or head-batched 3-D operand (input of the f16x3 scheme's scale)."""
-    out = torch.zeros(1, dtype=torch.float32, device=a.device)
+    out = torch.empty(1, dtype=torch.float32, device=a.device)
     if a.dim() == 3:
         hb, m, k = a.shape
         _lib.call("disgat_amax", a.data_ptr(), a.stride(1), a.stride(0), m, k, hb, out.data_ptr(), ops._stream())
@@ -45,13 +45,15 @@ def amax_for(a):
 def split_weight_f16(w):
     """[..., K, N] fp32 -> (int16 view of fp16 planes [..., 2, N, K] = hi, lo of w^T * s, device scalar s).
     s is the power of two that puts max |w| in [2^13, 2^14); lo carries an extra 2^11 (see gemm_f16x3_kernel)."""
-    wt = w.detach().transpose(-1, -2).contiguous()
-    mx = wt.abs().amax().clamp_min(1e-30)
-    s = torch.exp2(13.0 - torch.floor(torch.log2(mx))).reshape(1)
-    t = wt * s
-    hi = t.to(torch.float16)
-    lo = ((t - hi.float()) * 2048.0).to(torch.float16)
-    return torch.stack([hi, lo], dim=-3).contiguous().view(torch.int16), s
+    w = w.detach()
+    if w.dim() == 2:
+        w = w.unsqueeze(0)
+    hb, k, n = w.shape
+    planes = torch.empty((hb, 2, n, k), dtype=torch.int16, device=w.device)
+    amax_scale = torch.empty(2, dtype=torch.float32, device=w.device)
+    _lib.call("disgat_split_f16", w.data_ptr(), w.stride(0), w.stride(1), w.stride(2), k, n, hb, planes.data_ptr(),
+              amax_scale.data_ptr(), ops._stream())
+    return planes, amax_scale[1:]
 
 
 def split_weight(w):
@@ -78,7 +80,15 @@ def _kernel_ok(a, k, n):
             and (a.dim() == 2 or a.stride(0) % 4 == 0))
 
 
-def _forward(a, w, bias, init, act, slope, a_amax=None):
+def presplit(w):
+    """Split planes of a weight for reuse across calls (inference: the weights do not change between forwards);
+    None when the active scheme has nothing to precompute for it."""
+    if mode() != "f16x3" or not w.is_cuda or w.shape[-1] % 128 or w.shape[-2] % 32:
+        return None
+    return split_weight_f16(w)
+
+
+def _forward(a, w, bias, init, act, slope, a_amax=None, w_split=None):
     batched = a.dim() == 3
     if batched:
         hb, m, k = a.shape
@@ -107,7 +117,7 @@ def _forward(a, w, bias, init, act, slope, a_amax=None):
     if bias is not None:
         bias = bias.contiguous()
     if mode() == "f16x3":
-        planes, b_scale = split_weight_f16(w)
+        planes, b_scale = w_split if w_split is not None else split_weight_f16(w)
         if a_amax is None:
             a_amax = amax(a)
         _lib.call("disgat_gemm_f16x3", a.data_ptr(), a.stride(-2), a.stride(0) if batched else 0, planes.data_ptr(),
@@ -136,8 +146,8 @@ def _act_backward(g, out, act, slope):
 
 class _Linear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, a, w, bias, init, act, slope, a_amax=None):
-        out = _forward(a, w, bias, init, act, slope, a_amax)
+    def forward(ctx, a, w, bias, init, act, slope, a_amax=None, w_split=None):
+        out = _forward(a, w, bias, init, act, slope, a_amax, w_split)
         ctx.save_for_backward(a, w, out if act != ACT_NONE else None)
         ctx.meta = (act, slope, bias is not None, init is not None)
         ctx.init_shared = init is not None and a.dim() == 3 and init.shape[1] != out.shape[1]
@@ -169,10 +179,11 @@ class _Linear(torch.autograd.Function):
             gb = g.sum(0)
         if has_init and ctx.needs_input_grad[3]:
             gi = g.view(g.shape[0], a.shape[0], -1).sum(1) if ctx.init_shared else g
-        return ga, gw, gb, gi, None, None, None
+        return ga, gw, gb, gi, None, None, None, None
 
 
-def linear(a, w, bias=None, init=None, act=ACT_NONE, slope=0.01, a_amax=None):
+def linear(a, w, bias=None, init=None, act=ACT_NONE, slope=0.01, a_amax=None, w_split=None):
     """act(a @ w + bias + init); see module docstring for the batched form (bias then is [H*N]).
-    a_amax: optional precomputed amax(a) when the same operand feeds several GEMMs."""
-    return _Linear.apply(a, w, bias, init, act, slope, a_amax)
+    a_amax: optional precomputed amax(a) (or an upper bound) when the same operand feeds several GEMMs;
+    w_split: optional presplit(w) to reuse."""
+    return _Linear.apply(a, w, bias, init, act, slope, a_amax, w_split)

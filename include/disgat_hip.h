@@ -163,10 +163,15 @@ int disgat_gemm_f16x3(const float* A, int64_t lda, int64_t a_batch_stride, const
                       int64_t ldi, int64_t init_batch_stride, float* C, int64_t ldc, int64_t c_batch_stride,
                       int M, int N, int K, int batch, int act, float slope, disgat_stream_t stream);
 
-/* *out = max(*out, max |A[b][m][k]|) over batch x M x K (K, lda, batch stride multiples of 4); the caller
- * zeroes *out first. */
+/* *out = max |A[b][m][k]| over batch x M x K (K, lda, batch stride multiples of 4); 0 for an empty operand. */
 int disgat_amax(const float* A, int64_t lda, int64_t a_batch_stride, int M, int K, int batch, float* out,
                 disgat_stream_t stream);
+
+/* Weight preparation for disgat_gemm_f16x3: W is [batch][K][N] fp32 with arbitrary element strides.  Writes
+ * planes [batch][2][N][K] fp16 = hi, lo of (W^T * s) and amax_scale[0] = max |W|, amax_scale[1] = s (pass
+ * amax_scale + 1 as b_scale). */
+int disgat_split_f16(const float* W, int64_t stride_b, int64_t stride_k, int64_t stride_n, int K, int N, int batch,
+                     uint16_t* planes, float* amax_scale, disgat_stream_t stream);
 
 /* Backward of the epilogue activation from the saved output (n contiguous floats, n % 4 == 0):
  * gin = g * (out > 0 ? 1 : (act == 1 ? out + 1 : slope)); act 1 = ELU, 2 = leaky ReLU.  gin may alias g. */

@@ -131,10 +131,10 @@ def test_analytic_operand_bounds_hold(gnn, train):
     seen = []
     real = ops_gemm._forward
 
-    def spy(a, w, bias, init, act, slope, a_amax=None):
+    def spy(a, w, bias, init, act, slope, a_amax=None, w_split=None):
         if a_amax is not None:
             seen.append((float(a.abs().max()), float(a_amax)))
-        return real(a, w, bias, init, act, slope, a_amax)
+        return real(a, w, bias, init, act, slope, a_amax, w_split)
 
     ops_gemm._forward = spy
     try:
