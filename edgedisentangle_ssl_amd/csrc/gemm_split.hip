@@ -479,9 +479,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(const GemmHArgs G) {
 // of the HBM write rate (~21 GB/s): a wave's 64 stores per N-step block in the issue queue, and the other wave's B
 // fragment loads queue behind them in the same vector-memory path (no epilogue: -1.5 ms; no B reloads: -1.0 ms).
 // Tried without gain: issuing all LDS fragment reads ahead of the MFMAs (the two waves per SIMD already hide that
-// latency) and a per-SIMD token that forces the two waves into anti-phase (MFMA loop vs stores).  The next step is
-// to retire the previous N-step's results a few stores per k-step inside the next MFMA loop (needs a second
-// accumulator set, i.e. a 64 x 32 wave tile).
+// latency), a per-SIMD token that forces the two waves into anti-phase (MFMA loop vs stores), and a variant with
+// 64 x 32 wave tiles and two accumulator sets that retires the previous step's results 4 stores per k-step inside
+// the next MFMA loop (correct, 4.6 ms against 3.5: twice the B-fragment traffic and twice the steps cost more than
+// the overlap returns).
 constexpr int AS_BM = 128, AS_PAD = 8;     // LDS row = K + 8 fp16: row stride = 4 banks mod 64 -> conflict-free b128 reads
 
 template <int ACT>
