@@ -25,6 +25,11 @@
  *                       836; trainer.py:200).  Gather-only segment passes, see csrc/edge_bwd.hip.
  *  disgat_pair_loss     sigmoid(sum of heads) + utils.adj_mse_loss partial sums
  *                       (pretrainer.py:727-739, 612-627; utils.py:287-298).
+ *  disgat_gemm_f16x3,   the dense contractions of the path - torch.mm / nn.Linear at layers.py:350, 363, 376,
+ *  disgat_gemm_split,   398, 110, 39, 905 and models.py:538 (ATen fp32 GEMM) - as fp32-accurate GEMMs on the
+ *  disgat_split_f16,    16-bit matrix cores (operand splitting), with the bias / additive / ELU (layers.py:508)
+ *  disgat_amax,         / leaky-ReLU (layers.py:917, models.py:535) epilogues fused; weight preparation, the
+ *  disgat_act_bwd       scale input and the activation's backward.
  *
  * Layouts (all row-major fp32 unless noted; "ld*" = row stride in floats, a multiple of 4,
  * base pointers 16-byte aligned):
