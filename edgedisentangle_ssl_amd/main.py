@@ -58,6 +58,9 @@ def run(argv=None, log=print):
 
     encoder = models.DISGAT(args, nfeat=args.size, nhid=args.nhid, nclass=args.nhid, nheads=args.nhead,
                             dropout=args.dropout).to(dev)                  # main.py:142-147
+    # SupEdge / DisEdge only read the aux scores of predict_adjs_sparse: skip the layer-2 aggregation + fuser the
+    # reference computes and discards there (same losses and gradients, ~12 % less work per SSL step)
+    encoder.skip_unused = True
     ssl_trainers, ssl_labels = [], []
     for i, name in enumerate(args.pretrain or []):                        # main.py:242-251
         assert args.pre_edge[i] > 0, "edge index begins from 1"
