@@ -18,7 +18,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops, ops_gemm, parallel
-from .graph import CSRGraph, graph_of
+from .graph import graph_of
 
 
 def _pow2ceil(v):

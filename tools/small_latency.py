@@ -6,7 +6,6 @@ import sys
 import time
 from types import SimpleNamespace
 
-import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -10,7 +10,6 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
-from edgedisentangle_ssl_amd import ops  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--nodes", type=int, default=200_000)
