@@ -237,10 +237,23 @@ __global__ __launch_bounds__(256) void edge_combine_kernel(const int32_t* __rest
     const int h = idx / F_in;
     float den = 0.f, dsum = 0.f;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int sl = s0; sl < s1; ++sl) {
-      den += part_den[(size_t)sl * (2 * H) + h];
-      dsum += part_den[(size_t)sl * (2 * H) + H + h];
-      acc += ld4(part_z + (size_t)sl * HF + idx);
+    for (int sl = s0; sl < s1; sl += 8) {          // 8 independent loads in flight (a hub row has hundreds of slices),
+      f32x4 pz[8];                                  // summed in slice order: deterministic
+      float pd[8], ps[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int q = min(sl + u, s1 - 1);
+        pz[u] = ld4(part_z + (size_t)q * HF + idx);
+        pd[u] = part_den[(size_t)q * (2 * H) + h];
+        ps[u] = part_den[(size_t)q * (2 * H) + H + h];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (sl + u < s1) {
+          acc += pz[u];
+          den += pd[u];
+          dsum += ps[u];
+        }
     }
     float inv = (den > 0.f) ? 1.0f / den : 0.f;
     if (sage_div) inv = inv / (dsum * inv + 1.0f);

@@ -702,12 +702,24 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ A, 
                                                    int M, int K4, uint32_t* __restrict__ out) {
   uint32_t m = 0u;
   const int64_t total = rows * K4;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int64_t r = i / K4;
-    const int c = (int)(i - r * K4) * 4;
-    const int64_t bz = r / M, rm = r - bz * M;
-    const f32x4 v = ld4(A + bz * a_bs + rm * lda + c);
+  auto upd = [&](const f32x4 v) {
     m = max(max(m, __float_as_uint(fabsf(v.x))), max(__float_as_uint(fabsf(v.y)), max(__float_as_uint(fabsf(v.z)), __float_as_uint(fabsf(v.w)))));
+  };
+  if (lda == (int64_t)K4 * 4 && (rows == M || a_bs == (int64_t)M * lda)) {      // dense: one flat sweep, 4 loads in flight
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < total; i += 4 * stride) {
+      const f32x4 v0 = ld4(A + i * 4), v1 = ld4(A + (i + stride) * 4), v2 = ld4(A + (i + 2 * stride) * 4), v3 = ld4(A + (i + 3 * stride) * 4);
+      upd(v0); upd(v1); upd(v2); upd(v3);
+    }
+    for (; i < total; i += stride) upd(ld4(A + i * 4));
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+      const int64_t r = i / K4;
+      const int c = (int)(i - r * K4) * 4;
+      const int64_t bz = r / M, rm = r - bz * M;
+      upd(ld4(A + bz * a_bs + rm * lda + c));
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
