@@ -147,3 +147,31 @@ def test_analytic_operand_bounds_hold(gnn, train):
         assert bound >= true_max, (true_max, bound)
     assert float(heads.fused_amax) >= float(heads.fused.abs().max())
     assert torch.isfinite(heads.fused).all()
+
+
+def test_weight_split_reconstructs_strided_and_expanded_weights():
+    """disgat_split_f16 on a transposed view, a column slice and a stride-0 head expansion: hi + lo * 2^-11 must
+    reproduce w * s to 2^-22 of each element, s a power of two placing max |w| in [2^13, 2^14)."""
+    from edgedisentangle_ssl_amd import ops_gemm
+    g = torch.Generator(device="cuda").manual_seed(5)
+    base = torch.randn(300, 200, device="cuda", generator=g) * 3.0
+    cases = [base, base.t(), base[:, 40:168], base[::2, :].t().unsqueeze(0).expand(4, 200, 150)]
+    for w in cases:
+        planes, s = ops_gemm.split_weight_f16(w)
+        w3 = w if w.dim() == 3 else w.unsqueeze(0)
+        p = planes.view(torch.float16).float()                       # [hb, 2, N, K]
+        rec = (p[:, 0] + p[:, 1] / 2048.0).transpose(1, 2)            # [hb, K, N]
+        ref = w3 * s
+        assert float(s) == 2.0 ** round(float(torch.log2(s)))        # a power of two
+        assert 2.0 ** 13 <= float((w3.abs().max() * s)) < 2.0 ** 14
+        assert float(((rec - ref).abs() / ref.abs().clamp_min(1e-3)).max()) < 2.0 ** -21
+
+
+def test_amax_batched_strided_view():
+    from edgedisentangle_ssl_amd import ops_gemm
+    z = torch.randn(777, 8, 64, device="cuda")
+    z[123, 5, 17] = -99.5
+    zt = z.permute(1, 0, 2)                                           # [H, M, K] strided, as the projection GEMM sees Z
+    assert float(ops_gemm.amax(zt)) == 99.5
+    assert float(ops_gemm.amax(z.view(777, 512))) == 99.5
+    assert float(ops_gemm.amax(torch.zeros(10, 64, device="cuda"))) == 0.0
