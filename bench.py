@@ -56,6 +56,13 @@ def make_args(o):
                            sparse=True, model="DISGAT", dis_type=1, lr=0.01, weight_decay=5e-4)
 
 
+def ops_gemm_mode():
+    """Which fp32-equivalent GEMM scheme the dense contractions ran on: f16x3 = two fp16 planes per
+    operand, 3 MFMA products, fp32 accumulation; measured error vs fp64 at or below hipBLASLt's fp32 GEMM."""
+    from edgedisentangle_ssl_amd import ops_gemm
+    return ops_gemm.mode()
+
+
 def sharded_graph(o, rank, world, dev):
     """Rows of this rank in a world-times larger power-law graph (local generation, no exchange):
     the symmetrised generator of SURVEY 8(d) gives row i its own power-law out-entries (uniform
@@ -316,6 +323,7 @@ def main():
                                + ("BASELINE configs[3] graph on 1 GPU" if world == 1 else f"row-sharded over {world} GPUs"),
                    "nodes_per_rank": o.nodes, "nnz_total": int(nnz_total), "feat": o.feat, "heads": o.heads,
                    "att": o.att, "gnn_type": o.gnn_type, "parallelism": f"row-range x{world}",
+                   "gemm_scheme": ops_gemm_mode(),
                    "csr_build_ms": None if getattr(graph, "prep_ms", None) is None else round(graph.prep_ms, 1)},
         "roofline": roof, "cpu_baseline": cpu,
     }
