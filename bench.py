@@ -63,6 +63,22 @@ def ops_gemm_mode():
     return ops_gemm.mode()
 
 
+def gemm_check(x, enc, dev):
+    """Max error of the path's GEMM scheme against float64 on the workload's own operands (first 8192 rows of x times
+    the first head's score weight), next to hipBLASLt's fp32 GEMM on the same data; relative to the output maximum."""
+    from edgedisentangle_ssl_amd import ops_gemm
+    with torch.no_grad():
+        a = x[:8192].contiguous()
+        w = torch.cat([l.W[: x.shape[1]] for l in enc.attentions1], dim=1).contiguous()
+        if w.shape[1] % 128 or a.shape[1] % 32:
+            return None
+        ref = a.double() @ w.double()
+        scale = float(ref.abs().max())
+        ours = float((ops_gemm.linear(a, w).double() - ref).abs().max()) / scale
+        blas = float(((a @ w).double() - ref).abs().max()) / scale
+    return {"ours_vs_fp64": ours, "hipblaslt_fp32_vs_fp64": blas, "sample": f"{a.shape[0]}x{a.shape[1]} @ {tuple(w.shape)}"}
+
+
 def sharded_graph(o, rank, world, dev):
     """Rows of this rank in a world-times larger power-law graph (local generation, no exchange):
     the symmetrised generator of SURVEY 8(d) gives row i its own power-law out-entries (uniform
@@ -311,6 +327,7 @@ def main():
     if not o.no_cpu_baseline and world == 1:          # rank 0, N=1 only (bench contract)
         cpu = cpu_baseline(o)
     ms = dt / o.steps * 1e3
+    gemm_chk = gemm_check(x, enc, dev) if rank == 0 else None
     what = "T_fwd(get_em)" if o.fwd_only else "T_iter(SupEdge+DisEdge+DifHead fwd+loss)"
     if o.skip_unused and not o.fwd_only:
         what += " with the discarded layer-2 aggregation of predict_adjs_sparse skipped (secondary definition)"
@@ -323,7 +340,7 @@ def main():
                                + ("BASELINE configs[3] graph on 1 GPU" if world == 1 else f"row-sharded over {world} GPUs"),
                    "nodes_per_rank": o.nodes, "nnz_total": int(nnz_total), "feat": o.feat, "heads": o.heads,
                    "att": o.att, "gnn_type": o.gnn_type, "parallelism": f"row-range x{world}",
-                   "gemm_scheme": ops_gemm_mode(),
+                   "gemm_scheme": ops_gemm_mode(), "gemm_check": gemm_chk,
                    "csr_build_ms": None if getattr(graph, "prep_ms", None) is None else round(graph.prep_ms, 1)},
         "roofline": roof, "cpu_baseline": cpu,
     }
