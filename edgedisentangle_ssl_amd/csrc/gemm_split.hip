@@ -1,9 +1,14 @@
-// fp32-accurate dense GEMM on the bf16 matrix cores of gfx950 (CDNA4 has no xf32/TF32 and its
-// f32-input MFMA runs at the vector rate, 1/16 of bf16).
+// fp32-accurate dense GEMMs on the 16-bit matrix cores of gfx950 (CDNA4 has no xf32/TF32 and its
+// f32-input MFMA runs at the vector rate, 1/16 of bf16 / fp16).
 //
 //   C[b] = act( A[b] (M x K, fp32) * B[b] (K x N) + bias[b] + init[b] )        b = 0 .. batch-1
 //
-// Every fp32 value v is written exactly as hi + mid + lo with three bf16 numbers (8 + 8 + 8
+// Two operand-splitting schemes live in this file: (1) below, three bf16 planes / six products, operands exact
+// (`DISGAT_GEMM=split6`); (2) further down, two scaled fp16 planes / three products, the default - its tiled
+// kernel for K > 256 and its A-stationary kernel for K <= 256 - plus the helpers (max |A|, weight preparation,
+// activation backward).
+//
+// Scheme 1.  Every fp32 value v is written exactly as hi + mid + lo with three bf16 numbers (8 + 8 + 8
 // mantissa bits); a product a*b then needs the six partial
 // products whose weight is >= 2^-16 (hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi), each exact in
 // the MFMA's fp32 accumulator; the dropped terms are <= 2^-25 relative, below fp32 rounding.
