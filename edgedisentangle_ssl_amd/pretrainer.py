@@ -22,6 +22,15 @@ from .models import MLP
 from .utils import adj_mse_loss
 
 
+def make_adam(params, args):
+    """The reference's per-module Adam (trainer.py:58-60) with torch's single-kernel (`fused`) step for device
+    parameters: a trainer owns 3-5 optimisers of a few tensors each and steps them all every train_step, which on
+    small graphs is mostly launch overhead."""
+    params = list(params)
+    fused = bool(params) and all(p.is_cuda for p in params)
+    return optim.Adam(params, lr=args.lr, weight_decay=args.weight_decay, **({"fused": True} if fused else {}))
+
+
 def pair_mse_loss(aux, h_lo, h_hi, labels, graph=None):
     """pred = sigmoid(sum_{h in [lo,hi)} aux_h); utils.adj_mse_loss(pred, labels) on 1-D input
     (pretrainer.py:734-739, 619-627).  aux: list of H [M,1] tensors (entries outside the range may
@@ -70,7 +79,7 @@ class Trainer(object):
         self.fuse1.to(dev)
         self.fuse2.to(dev)
         self.models += [self.fuse1, self.fuse2]
-        self.models_opt = [optim.Adam(m.parameters(), lr=args.lr, weight_decay=args.weight_decay) for m in self.models]
+        self.models_opt = [make_adam(m.parameters(), args) for m in self.models]
 
     def _begin_step(self):
         for i, model in enumerate(self.models):
@@ -204,7 +213,7 @@ class DifHeadTrainer(Trainer):
                                layers=args.cls_layer).to(dev)
         for c in (self.classifier1, self.classifier2):
             self.models.append(c)
-            self.models_opt.append(optim.Adam(c.parameters(), lr=args.lr, weight_decay=args.weight_decay))
+            self.models_opt.append(make_adam(c.parameters(), args))
         self.nhead = args.nhead
 
     def get_label_all(self, feature, adj):

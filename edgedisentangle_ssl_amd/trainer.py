@@ -5,10 +5,9 @@ import random
 import numpy as np
 import torch
 import torch.nn.functional as F
-import torch.optim as optim
 
 from .models import MLP
-from .pretrainer import Trainer
+from .pretrainer import Trainer, make_adam
 from .utils import accuracy
 
 
@@ -64,7 +63,7 @@ class ClsTrainer(Trainer):
         self.classifier = MLP(in_feat=self.in_dim, hidden_size=args.nhid, out_size=labels.max().item() + 1,
                               layers=args.cls_layer).to(dev)
         self.models.append(self.classifier)
-        self.models_opt.append(optim.Adam(self.classifier.parameters(), lr=args.lr, weight_decay=args.weight_decay))
+        self.models_opt.append(make_adam(self.classifier.parameters(), args))
         tr, va, te, self.class_num_mat = split(labels.cpu(), train_ratio=args.node_sup_ratio)
         self.idx_train, self.idx_val, self.idx_test = tr.to(dev), va.to(dev), te.to(dev)
 
