@@ -355,15 +355,17 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void seg_grad_hx_row_kernel(const 
   const int myh = lane & (H - 1);
   const bool hact = (myh >= A.h_lo) && (myh < A.h_hi);
   f32x4 acc[H * XN], xA[XN], xB[XN];
+  float cA, cB;      // the position's coefficients travel with its operand row through the 2-deep pipeline (loaded in
+                     // compute() their latency was exposed once per position)
 #pragma unroll
   for (int i = 0; i < H * XN; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  auto load_x = [&](f32x4(&xv)[XN], int o) {
+  auto load_x = [&](f32x4(&xv)[XN], float& cf, int o, int gpos) {
     const float* xp = A.otherop + (size_t)o * A.ld_other + xoff;
 #pragma unroll
     for (int i = 0; i < XN; ++i) xv[i] = (i * 256 + xoff < A.F) ? ld4(xp + i * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
+    cf = (lane < H && hact) ? A.g[(int64_t)myh * A.g_stride + gpos] : 0.f;
   };
-  auto compute = [&](const f32x4(&xv)[XN], int gpos) {
-    const float cf = (lane < H && hact) ? A.g[(int64_t)myh * A.g_stride + gpos] : 0.f;
+  auto compute = [&](const f32x4(&xv)[XN], const float cf) {
 #pragma unroll
     for (int hh = 0; hh < H; ++hh) {
       const float c = readlane_f(cf, hh);
@@ -375,15 +377,15 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void seg_grad_hx_row_kernel(const 
     const int cnt = min(64, me - mbase);
     const int ov = (lane < cnt) ? A.other[mbase + lane] : 0;
     const int pv = (lane < cnt) ? (A.perm ? A.perm[mbase + lane] : mbase + lane) : 0;
-    load_x(xA, __builtin_amdgcn_readlane(ov, 0));
+    load_x(xA, cA, __builtin_amdgcn_readlane(ov, 0), __builtin_amdgcn_readlane(pv, 0));
     int i = 0;
     for (; i + 1 < cnt; i += 2) {
-      load_x(xB, __builtin_amdgcn_readlane(ov, i + 1));
-      compute(xA, __builtin_amdgcn_readlane(pv, i));
-      if (i + 2 < cnt) load_x(xA, __builtin_amdgcn_readlane(ov, i + 2));
-      compute(xB, __builtin_amdgcn_readlane(pv, i + 1));
+      load_x(xB, cB, __builtin_amdgcn_readlane(ov, i + 1), __builtin_amdgcn_readlane(pv, i + 1));
+      compute(xA, cA);
+      if (i + 2 < cnt) load_x(xA, cA, __builtin_amdgcn_readlane(ov, i + 2), __builtin_amdgcn_readlane(pv, i + 2));
+      compute(xB, cB);
     }
-    if (i < cnt) compute(xA, __builtin_amdgcn_readlane(pv, i));
+    if (i < cnt) compute(xA, cA);
   }
   float* op = A.gkey + (size_t)key * A.ld_gkey + xoff;
 #pragma unroll
@@ -406,9 +408,11 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void seg_grad_hx_col_kernel(const 
   const int myh = lane & (H - 1);
   const bool hact = (myh >= A.h_lo) && (myh < A.h_hi);
   f32x4 acc[XN], mA[H * XN], mB[H * XN];
+  float cA, cB;      // coefficients prefetched with the operand row (see seg_grad_hx_row_kernel)
 #pragma unroll
   for (int i = 0; i < XN; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  auto load_m = [&](f32x4(&mv)[H * XN], int o) {
+  auto load_m = [&](f32x4(&mv)[H * XN], float& cf, int o, int gpos) {
+    cf = (lane < H && hact) ? A.g[(int64_t)myh * A.g_stride + gpos] : 0.f;
     const float* mp = A.otherop + (size_t)o * A.ld_other + xoff;
 #pragma unroll
     for (int hh = 0; hh < H; ++hh)
@@ -418,8 +422,7 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void seg_grad_hx_col_kernel(const 
           mv[hh * XN + i] = (i * 256 + xoff < A.F) ? ld4(mp + hh * A.F + i * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
   };
-  auto compute = [&](const f32x4(&mv)[H * XN], int gpos) {
-    const float cf = (lane < H && hact) ? A.g[(int64_t)myh * A.g_stride + gpos] : 0.f;
+  auto compute = [&](const f32x4(&mv)[H * XN], const float cf) {
 #pragma unroll
     for (int hh = 0; hh < H; ++hh)
       if (hh >= A.h_lo && hh < A.h_hi) {
@@ -432,15 +435,15 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void seg_grad_hx_col_kernel(const 
     const int cnt = min(64, me - mbase);
     const int ov = (lane < cnt) ? A.other[mbase + lane] : 0;
     const int pv = (lane < cnt) ? (A.perm ? A.perm[mbase + lane] : mbase + lane) : 0;
-    load_m(mA, __builtin_amdgcn_readlane(ov, 0));
+    load_m(mA, cA, __builtin_amdgcn_readlane(ov, 0), __builtin_amdgcn_readlane(pv, 0));
     int i = 0;
     for (; i + 1 < cnt; i += 2) {
-      load_m(mB, __builtin_amdgcn_readlane(ov, i + 1));
-      compute(mA, __builtin_amdgcn_readlane(pv, i));
-      if (i + 2 < cnt) load_m(mA, __builtin_amdgcn_readlane(ov, i + 2));
-      compute(mB, __builtin_amdgcn_readlane(pv, i + 1));
+      load_m(mB, cB, __builtin_amdgcn_readlane(ov, i + 1), __builtin_amdgcn_readlane(pv, i + 1));
+      compute(mA, cA);
+      if (i + 2 < cnt) load_m(mA, cA, __builtin_amdgcn_readlane(ov, i + 2), __builtin_amdgcn_readlane(pv, i + 2));
+      compute(mB, cB);
     }
-    if (i < cnt) compute(mA, __builtin_amdgcn_readlane(pv, i));
+    if (i < cnt) compute(mA, cA);
   }
   float* op = A.gkey + (size_t)key * A.ld_gkey + xoff;
 #pragma unroll
