@@ -105,6 +105,24 @@ def edge_backward(ctx, gz, ge):
     return g_x, g_row, g_col, g_a, None
 
 
+_SEG_CACHE = {}          # (storage ptr, M, version, side, n_keys, chunk) -> (pairs kept alive, result); FIFO of 8
+
+
+def _segments_of(pairs, side, n_keys, chunk):
+    """_segments(pairs[side]) memoised per pair list: the same list is scored by both layers of a pass, so its
+    column-side sort (the expensive part) and work items are built once per training step instead of once per layer.
+    The entry keeps `pairs` alive, so its storage pointer cannot be recycled while the entry exists."""
+    key = (pairs.data_ptr(), int(pairs.shape[1]), pairs._version, side, n_keys, chunk)
+    hit = _SEG_CACHE.get(key)
+    if hit is not None:
+        return hit[1]
+    res = _segments(pairs[side], n_keys, chunk)
+    if len(_SEG_CACHE) >= 8:
+        _SEG_CACHE.pop(next(iter(_SEG_CACHE)))
+    _SEG_CACHE[key] = (pairs, res)
+    return res
+
+
 def _segments(keys, n_keys, chunk):
     """Work items over a key-sorted list + the int32 permutation that sorts it (None if sorted)."""
     m = keys.numel()
@@ -143,10 +161,10 @@ def aux_backward(ctx, gout):
     sign = getattr(ctx, "sign", None)
     if att == 3 and sign is not None:                   # gather-free: only the keys and the sign record are read
         if need_row or need_a:
-            wi, _perm, perm32 = _segments(rows, n_rows, chunk)
+            wi, _perm, perm32 = _segments_of(pairs, 0, n_rows, chunk)
             g_row, g_a = _seg_sign(wi, perm32, gout, lo, hi, H, f_out, sign, rowop, a, n_rows, need_a)
         if need_col or need_a:
-            wi, _perm, perm32 = _segments(cols, n_cols, chunk)
+            wi, _perm, perm32 = _segments_of(pairs, 1, n_cols, chunk)
             g_col, ga_c = _seg_sign(wi, perm32, gout, lo, hi, H, f_out, sign, colop, a, n_cols, need_a)
             g_a = g_a + ga_c if need_a else None
         return g_x, g_row, g_col, g_a, None, None
