@@ -105,6 +105,8 @@ _SIGS = {
     "disgat_gemm_f16x3": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _P, _P, _P, _P, _P, _c.c_int64, _c.c_int64, _P,
                                      _c.c_int64, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
                                      _c.c_float, _P]),
+    "disgat_gemm_f16x3_tn": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _P, _c.c_int64, _c.c_int64, _P, _P, _P, _c.c_int, _c.c_int,
+                                        _c.c_int, _c.c_int, _c.c_int, _P]),
     "disgat_split_f16": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _P, _P, _P]),
     "disgat_amax": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _P, _P]),
     "disgat_act_bwd": (_c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int, _c.c_float, _P]),

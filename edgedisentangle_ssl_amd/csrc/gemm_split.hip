@@ -668,6 +668,148 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x3_as_kernel(const GemmHArgs G
   }
 }
 
+// Weight gradient dW[Ka][N] = A^T G with A [M][Ka], G [M][N] both fp32 and both "k-major" (the reduction index M
+// is the ROW of either operand), M ~ 1e6: split-K over row ranges, deterministic partial sums reduced by the host.
+// Both operands are split on the fly (same two-plane fp16 scheme, scales from their max magnitudes) into LDS images
+// [32 k-rows][128 cols] and consumed through gfx950's transposing LDS read `ds_read_b64_tr_b16`: per 16-lane group
+// it takes a 4 x 16 block and hands lane i the 4 k-values of column i - two of them are one 16x16x32 operand
+// fragment.  256-byte image rows with the XOR chunk swizzle of the CDNA4 guide (T10, image (b)) keep both the 8-byte
+// stores and the transposed reads conflict-free.
+typedef __fp16 trh4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+
+struct GemmTNArgs {
+  const float* A;
+  int64_t lda, a_bs;
+  const float* G;
+  int64_t ldg, g_bs;
+  const float* a_amax;
+  const float* g_amax;
+  float* part;            // [batch][S][Ka][N]
+  int M, Ka, N, batch, S, rows_per_split;
+};
+
+__device__ __forceinline__ int tn_off(int row, int ch) {        // byte offset of 16-byte chunk ch of image row `row`
+  return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_f16x3_tn_kernel(const GemmTNArgs T) {
+  __shared__ __attribute__((aligned(16))) unsigned char img[4 * 8192];     // A hi, A lo, G hi, G lo: 32 rows x 256 B
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nt = T.N / 128;
+  const int ka0 = (blockIdx.x / nt) * 128, n0 = (blockIdx.x % nt) * 128;
+  const int sp = blockIdx.y, bz = blockIdx.z;
+  const int k_begin = sp * T.rows_per_split;
+  const int k_end = min(T.M, k_begin + T.rows_per_split);
+
+  const float* A = T.A + (int64_t)bz * T.a_bs + ka0;
+  const float* G = T.G + (int64_t)bz * T.g_bs + n0;
+  const float sA = f16_scale(*T.a_amax), sG = f16_scale(*T.g_amax);
+  const float inv = 1.0f / (sA * sG);
+
+  // staging: thread t covers rows (t >> 5) + 8 i (i < 4), columns 4 (t & 31) .. +3 of both 32 x 128 tiles
+  const int s_row = tid >> 5, s_col = (tid & 31) * 4;
+  f32x4 a_s[4], g_s[4];
+  auto load = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = k0 + s_row + 8 * i;
+      const bool ok = k < k_end;
+      a_s[i] = ok ? ld4(A + (int64_t)k * T.lda + s_col) : f32x4{0.f, 0.f, 0.f, 0.f};
+      g_s[i] = ok ? ld4(G + (int64_t)k * T.ldg + s_col) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto store = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int o = tn_off(s_row + 8 * i, s_col >> 3) + (s_col & 4) * 2;
+      u32x2 h, l;
+      split4h(a_s[i] * sA, h, l);
+      *reinterpret_cast<u32x2*>(img + o) = h;
+      *reinterpret_cast<u32x2*>(img + 8192 + o) = l;
+      split4h(g_s[i] * sG, h, l);
+      *reinterpret_cast<u32x2*>(img + 16384 + o) = h;
+      *reinterpret_cast<u32x2*>(img + 24576 + o) = l;
+    }
+  };
+
+  // transposed fragment read: lane (group g, q, p) addresses row r0 + q, columns c0 + 4p .. +3; lane i of the group
+  // receives column c0 + i of rows r0 .. r0+3.  Two reads (r0 = 8g, 8g + 4) = the 8 k-values of a 16x16x32 operand.
+  const int g4 = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
+  auto frag = [&](int image, int ch0) {
+    typedef __attribute__((address_space(3))) trh4* lptr;
+    const int o0 = image * 8192 + tn_off(8 * g4 + q4, ch0 + (p4 >> 1)) + 8 * (p4 & 1);
+    const int o1 = image * 8192 + tn_off(8 * g4 + 4 + q4, ch0 + (p4 >> 1)) + 8 * (p4 & 1);
+    const trh4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lptr)(img + o0));
+    const trh4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lptr)(img + o1));
+    f16x8 r;
+    r[0] = (_Float16)lo4[0]; r[1] = (_Float16)lo4[1]; r[2] = (_Float16)lo4[2]; r[3] = (_Float16)lo4[3];
+    r[4] = (_Float16)hi4[0]; r[5] = (_Float16)hi4[1]; r[6] = (_Float16)hi4[2]; r[7] = (_Float16)hi4[3];
+    return r;
+  };
+
+  f32x4v acc[4][4], acx[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+      acx[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    }
+
+  auto compute = [&]() {
+    f16x8 ah[4], gh[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ah[i] = frag(0, 8 * wm + 2 * i);
+      gh[i] = frag(2, 8 * wn + 2 * i);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], gh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f16x8 gl = frag(3, 8 * wn + 2 * j);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], gl, acx[i][j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f16x8 al = frag(1, 8 * wm + 2 * i);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, gh[j], acx[i][j], 0, 0, 0);
+    }
+  };
+
+  if (k_begin < k_end) {
+    load(k_begin);
+    store();
+    __syncthreads();
+    for (int k0 = k_begin; k0 < k_end; k0 += 32) {
+      const bool more = k0 + 32 < k_end;
+      if (more) load(k0 + 32);
+      compute();
+      __syncthreads();
+      if (more) {
+        store();
+        __syncthreads();
+      }
+    }
+  }
+
+  float* P = T.part + (((int64_t)bz * T.S + sp) * T.Ka + ka0 + 64 * wm) * T.N + n0 + 64 * wn;
+  const float xw = inv * (1.0f / 2048.f);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        P[(int64_t)(16 * i + 4 * (lane >> 4) + r) * T.N + 16 * j + (lane & 15)] = fmaf(acx[i][j][r], xw, acc[i][j][r] * inv);
+}
+
 // Weight preparation for the f16x3 scheme in two small launches (the torch formulation took ~15): max |W| over an
 // arbitrarily strided [batch][K][N] weight, then hi / lo planes of (W^T * s) as [batch][2][N][K] fp16 and s itself.
 __global__ __launch_bounds__(256) void wamax_kernel(const float* __restrict__ W, int64_t sb, int64_t sk, int64_t sn, int K,
@@ -860,4 +1002,21 @@ extern "C" int disgat_gemm_f16x3(const float* A, int64_t lda, int64_t a_batch_st
   }
   hipLaunchKernelGGL(gemm_f16x3_kernel, dim3((unsigned)blocks, batch), dim3(256), 0, st, G);
   return check_launch("gemm_f16x3_kernel");
+}
+
+extern "C" int disgat_gemm_f16x3_tn(const float* A, int64_t lda, int64_t a_batch_stride, const float* G, int64_t ldg,
+                                    int64_t g_batch_stride, const float* a_amax, const float* g_amax, float* partials,
+                                    int M, int Ka, int N, int batch, int splits, disgat_stream_t stream) {
+  using namespace disgat;
+  if (M == 0 || batch == 0) return 0;
+  DISGAT_REQUIRE(A && G && a_amax && g_amax && partials && M > 0 && batch > 0 && splits > 0, "gemm_f16x3_tn: null pointer / bad sizes");
+  DISGAT_REQUIRE(Ka > 0 && Ka % 128 == 0 && N > 0 && N % 128 == 0, "gemm_f16x3_tn: Ka=%d and N=%d must be multiples of 128", Ka, N);
+  DISGAT_REQUIRE(lda % 4 == 0 && ldg % 4 == 0 && a_batch_stride % 4 == 0 && g_batch_stride % 4 == 0 && aligned16(A) && aligned16(G),
+                 "gemm_f16x3_tn: operand rows must be 16-byte aligned");
+  const int rows = ((M + splits - 1) / splits + 31) / 32 * 32;
+  GemmTNArgs T{A, lda, a_batch_stride, G, ldg, g_batch_stride, a_amax, g_amax, partials, M, Ka, N, batch, splits, rows};
+  DISGAT_REQUIRE(splits < 65536 && batch < 65536, "gemm_f16x3_tn: grid too large");
+  hipLaunchKernelGGL(gemm_f16x3_tn_kernel, dim3((unsigned)((Ka / 128) * (N / 128)), splits, batch), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), T);
+  return check_launch("gemm_f16x3_tn_kernel");
 }

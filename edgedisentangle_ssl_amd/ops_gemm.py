@@ -144,11 +144,35 @@ def _act_backward(g, out, act, slope):
     return gin
 
 
+def _tn_ok(a, g, k, n):
+    return (mode() == "f16x3" and a.is_cuda and a.dtype == torch.float32 and g.dtype == torch.float32 and k % 128 == 0
+            and n % 128 == 0 and a.stride(-1) == 1 and g.stride(-1) == 1 and a.stride(-2) % 4 == 0 and g.stride(-2) % 4 == 0
+            and a.data_ptr() % 16 == 0 and g.data_ptr() % 16 == 0
+            and (a.dim() == 2 or (a.stride(0) % 4 == 0 and g.stride(0) % 4 == 0)) and a.shape[-2] >= 4096)
+
+
+def _weight_grad(a, g, a_amax, g_amax):
+    """a^T @ g reducing over the rows (a [M,K] / [H,M,K], g [M,N] / [H,M,N] view) on the split-K f16x3 kernel."""
+    batched = a.dim() == 3
+    hb = a.shape[0] if batched else 1
+    m, k = a.shape[-2:]
+    n = g.shape[-1]
+    tiles = (k // 128) * (n // 128) * hb
+    splits = max(1, min(64, -(-1024 // tiles), m // 2048))
+    part = torch.empty((hb, splits, k, n), dtype=torch.float32, device=a.device)
+    _lib.call("disgat_gemm_f16x3_tn", a.data_ptr(), a.stride(-2), a.stride(0) if batched else 0, g.data_ptr(), g.stride(-2),
+              g.stride(0) if batched else 0, a_amax.data_ptr(), g_amax.data_ptr(), part.data_ptr(), m, k, n, hb, splits,
+              ops._stream())
+    out = part.sum(1) if splits > 1 else part[:, 0]
+    return out if batched else out[0]
+
+
 class _Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, w, bias, init, act, slope, a_amax=None, w_split=None):
         out = _forward(a, w, bias, init, act, slope, a_amax, w_split)
         ctx.save_for_backward(a, w, out if act != ACT_NONE else None)
+        ctx.a_amax = a_amax
         ctx.meta = (act, slope, bias is not None, init is not None)
         ctx.init_shared = init is not None and a.dim() == 3 and init.shape[1] != out.shape[1]
         return out
@@ -163,18 +187,27 @@ class _Linear(torch.autograd.Function):
         # grad of the data operand: the same split-bf16 GEMM with the transposed weight (falls back to hipBLASLt
         # through _forward's own shape check); the weight gradient reduces over the million-row dimension and
         # stays on hipBLASLt.
+        # one max |g| pass serves both GEMMs below
+        g_am = amax(g) if (mode() == "f16x3" and g.is_cuda and g.dim() == 2 and g.is_contiguous() and g.shape[1] % 4 == 0
+                           and g.data_ptr() % 16 == 0) else None
         if a.dim() == 3:
             hb, m, k = a.shape
             g3 = g.view(m, hb, -1).permute(1, 0, 2)
             if ctx.needs_input_grad[0]:
-                ga = _forward(g3, w.transpose(1, 2), None, None, ACT_NONE, 0.0).view(m, hb, k).permute(1, 0, 2)
+                ga = _forward(g3, w.transpose(1, 2), None, None, ACT_NONE, 0.0, g_am).view(m, hb, k).permute(1, 0, 2)
             if ctx.needs_input_grad[1]:
-                gw = torch.bmm(a.transpose(1, 2), g3)
+                if g_am is not None and _tn_ok(a, g3, k, g3.shape[2]):
+                    gw = _weight_grad(a, g3, ctx.a_amax if ctx.a_amax is not None else amax(a), g_am)
+                else:
+                    gw = torch.bmm(a.transpose(1, 2), g3)
         else:
             if ctx.needs_input_grad[0]:
-                ga = _forward(g, w.t(), None, None, ACT_NONE, 0.0)
+                ga = _forward(g, w.t(), None, None, ACT_NONE, 0.0, g_am)
             if ctx.needs_input_grad[1]:
-                gw = a.t() @ g
+                if g_am is not None and _tn_ok(a, g, a.shape[1], g.shape[1]):
+                    gw = _weight_grad(a, g, ctx.a_amax if ctx.a_amax is not None else amax(a), g_am)
+                else:
+                    gw = a.t() @ g
         if has_bias and ctx.needs_input_grad[2]:
             gb = g.sum(0)
         if has_init and ctx.needs_input_grad[3]:

@@ -168,6 +168,14 @@ int disgat_gemm_f16x3(const float* A, int64_t lda, int64_t a_batch_stride, const
                       int64_t ldi, int64_t init_batch_stride, float* C, int64_t ldc, int64_t c_batch_stride,
                       int M, int N, int K, int batch, int act, float slope, disgat_stream_t stream);
 
+/* Weight gradient dW[b] = A[b]^T G[b] (A [M][Ka], G [M][N] fp32, the reduction runs over the M rows): split-K over
+ * `splits` row ranges with the f16x3 scheme, both operands split on the fly.  Writes partials [batch][splits][Ka][N];
+ * the caller sums them over `splits` (deterministic).  Ka, N multiples of 128; a_amax / g_amax: device floats holding
+ * (upper bounds of) max |A|, max |G|.  Replaces ATen's mm(a.t(), g) in the autograd of nn.Linear / torch.mm. */
+int disgat_gemm_f16x3_tn(const float* A, int64_t lda, int64_t a_batch_stride, const float* G, int64_t ldg,
+                         int64_t g_batch_stride, const float* a_amax, const float* g_amax, float* partials,
+                         int M, int Ka, int N, int batch, int splits, disgat_stream_t stream);
+
 /* *out = max |A[b][m][k]| over batch x M x K (K, lda, batch stride multiples of 4); 0 for an empty operand. */
 int disgat_amax(const float* A, int64_t lda, int64_t a_batch_stride, int M, int K, int batch, float* out,
                 disgat_stream_t stream);

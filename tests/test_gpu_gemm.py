@@ -175,3 +175,36 @@ def test_amax_batched_strided_view():
     assert float(ops_gemm.amax(zt)) == 99.5
     assert float(ops_gemm.amax(z.view(777, 512))) == 99.5
     assert float(ops_gemm.amax(torch.zeros(10, 64, device="cuda"))) == 0.0
+
+
+@pytest.mark.parametrize("m,k,n", [(20000, 256, 384), (70001, 128, 2048), (9000, 2048, 128)])
+def test_weight_gradient_split_k_kernel(m, k, n):
+    """a^T g over the row dimension (gemm_f16x3_tn_kernel: transposing LDS reads, split-K partials) against float64,
+    hipBLASLt's fp32 as yardstick; ragged M (not a multiple of 32 or of the split size)."""
+    from edgedisentangle_ssl_amd import ops_gemm
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    a = torch.randn(m, k, device="cuda", generator=gen) * torch.exp(torch.randn(m, 1, device="cuda", generator=gen))
+    g = torch.randn(m, n, device="cuda", generator=gen) * 0.3
+    assert ops_gemm._tn_ok(a, g, k, n)
+    got = ops_gemm._weight_grad(a, g, ops_gemm.amax(a), ops_gemm.amax(g))
+    ref = a.double().t() @ g.double()
+    e_got, e_blas = _err(got, ref), _err(a.t() @ g, ref)
+    assert got.shape == (k, n)
+    assert e_got <= max(2.0 * e_blas, 3e-7), (e_got, e_blas)
+    assert torch.equal(got, ops_gemm._weight_grad(a, g, ops_gemm.amax(a), ops_gemm.amax(g)))      # deterministic
+
+
+def test_weight_gradient_batched_strided_through_autograd():
+    from edgedisentangle_ssl_amd import ops_gemm
+    gen = torch.Generator(device="cuda").manual_seed(12)
+    H, m, k, n = 4, 10000, 128, 256
+    z = torch.randn(m, H, k, device="cuda", generator=gen)
+    zt = z.permute(1, 0, 2)                                   # strided [H,M,K] view, as in disga_heads
+    w = (torch.randn(H, k, n, device="cuda", generator=gen) * 0.2).requires_grad_(True)
+    out = ops_gemm.linear(zt, w, None, None, ops_gemm.ACT_ELU)
+    wsum = torch.randn(m, H * n, device="cuda", generator=gen)
+    (gw,) = torch.autograd.grad((out * wsum).sum(), [w])
+    wr = w.detach().double().requires_grad_(True)
+    refo = torch.nn.functional.elu(torch.bmm(zt.double(), wr).permute(1, 0, 2).reshape(m, H * n))
+    (rg,) = torch.autograd.grad((refo * wsum.double()).sum(), [wr])
+    assert _err(gw, rg) < 2e-6
