@@ -414,22 +414,21 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void seg_grad_hx_col_kernel(const 
   auto load_m = [&](f32x4(&mv)[H * XN], float& cf, int o, int gpos) {
     cf = (lane < H && hact) ? A.g[(int64_t)myh * A.g_stride + gpos] : 0.f;
     const float* mp = A.otherop + (size_t)o * A.ld_other + xoff;
+    // every head's slice is loaded (heads outside [h_lo, h_hi) get a zero coefficient): testing the range per head put
+    // a branch and a full vmcnt(0) wait around each load
 #pragma unroll
     for (int hh = 0; hh < H; ++hh)
-      if (hh >= A.h_lo && hh < A.h_hi) {
 #pragma unroll
-        for (int i = 0; i < XN; ++i)
-          mv[hh * XN + i] = (i * 256 + xoff < A.F) ? ld4(mp + hh * A.F + i * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
-      }
+      for (int i = 0; i < XN; ++i)
+        mv[hh * XN + i] = (i * 256 + xoff < A.F) ? ld4(mp + hh * A.F + i * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
   };
   auto compute = [&](const f32x4(&mv)[H * XN], const float cf) {
 #pragma unroll
-    for (int hh = 0; hh < H; ++hh)
-      if (hh >= A.h_lo && hh < A.h_hi) {
-        const float c = readlane_f(cf, hh);
+    for (int hh = 0; hh < H; ++hh) {
+      const float c = readlane_f(cf, hh);
 #pragma unroll
-        for (int i = 0; i < XN; ++i) acc[i] += c * mv[hh * XN + i];
-      }
+      for (int i = 0; i < XN; ++i) acc[i] += c * mv[hh * XN + i];
+    }
   };
   for (int mbase = mb; mbase < me; mbase += 64) {
     const int cnt = min(64, me - mbase);
