@@ -106,15 +106,18 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void bwd_alpha_kernel(const BwdAlp
   const int ge = lane >> HL;
   float galk[H];                                     // galpha of the positions this lane owns
   auto compute = [&](const f32x4(&xv)[XN], int i) {
-    float gal = 0.f;
+    // the H dot products <gZ[r,h,:], x[c,:]> are reduced together by the transposed butterfly (head h's total lands
+    // in lane group h), then each lane fetches the total of ITS head (lane % H): ~12 cross-lane ops instead of H
+    // full 64-lane reductions
+    float part[H];
 #pragma unroll
     for (int hh = 0; hh < H; ++hh) {
       float acc = 0.f;
 #pragma unroll
       for (int t = 0; t < XN; ++t) acc = dot4(gz[hh * XN + t], xv[t], acc);
-      acc = group_sum<6>(acc);
-      gal = (myh == hh) ? acc : gal;
+      part[hh] = acc;
     }
+    const float gal = __shfl(multi_reduce<HL>(part), myh << (6 - HL), 64);
     const bool mine = (i & (GE - 1)) == ge;
     const int slot = i / GE;
 #pragma unroll

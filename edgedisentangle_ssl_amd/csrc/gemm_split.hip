@@ -882,7 +882,9 @@ namespace disgat {
 // Backward of the fused epilogue activation from the saved OUTPUT: gin = g * act'(pre-activation), with
 // ELU' = (out > 0 ? 1 : out + 1) (out + 1 = exp(v) for v <= 0) and leaky' = (out > 0 ? 1 : slope).
 __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ g, const float* __restrict__ out,
-                                                      float* __restrict__ gin, int64_t n4, int act, float slope) {
+                                                      float* __restrict__ gin, int64_t n4, int act, float slope,
+                                                      uint32_t* __restrict__ amax_out) {
+  uint32_t m = 0u;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
     const f32x4 gv = ld4(g + i * 4), o = ld4(out + i * 4);
     f32x4 r;
@@ -891,13 +893,23 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
     r.z = gv.z * (o.z > 0.f ? 1.f : (act == 1 ? o.z + 1.f : slope));
     r.w = gv.w * (o.w > 0.f ? 1.f : (act == 1 ? o.w + 1.f : slope));
     st4(gin + i * 4, r);
+    m = max(max(m, __float_as_uint(fabsf(r.x))), max(__float_as_uint(fabsf(r.y)), max(__float_as_uint(fabsf(r.z)), __float_as_uint(fabsf(r.w)))));
+  }
+  if (amax_out != nullptr) {          // max |gin| for the GEMMs that consume it (saves them a pass over gin)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m != 0u) atomicMax(amax_out, m);
   }
 }
 }  // namespace disgat
 
 extern "C" int disgat_act_bwd(const float* g, const float* out, float* gin, int64_t n, int act, float slope,
-                              disgat_stream_t stream) {
+                              float* amax_out, disgat_stream_t stream) {
   using namespace disgat;
+  if (amax_out != nullptr) {
+    const hipError_t e = hipMemsetAsync(amax_out, 0, sizeof(float), reinterpret_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail((int)e, "act_bwd: memset failed: %s", hipGetErrorString(e));
+  }
   if (n == 0) return 0;
   DISGAT_REQUIRE(g && out && gin && n > 0 && n % 4 == 0, "act_bwd: null pointer or n %% 4 != 0");
   DISGAT_REQUIRE(act == 1 || act == 2, "act_bwd: act=%d (1 = ELU, 2 = leaky ReLU)", act);
@@ -905,7 +917,7 @@ extern "C" int disgat_act_bwd(const float* g, const float* out, float* gin, int6
   const int64_t n4 = n / 4;
   const int grid = (int)((n4 + 255) / 256 < 65536 ? (n4 + 255) / 256 : 65536);
   hipLaunchKernelGGL(act_bwd_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), g, out, gin, n4,
-                     act, slope);
+                     act, slope, reinterpret_cast<uint32_t*>(amax_out));
   return check_launch("act_bwd_kernel");
 }
 

@@ -134,14 +134,16 @@ def _forward(a, w, bias, init, act, slope, a_amax=None, w_split=None):
 
 
 def _act_backward(g, out, act, slope):
-    """g * act'(.) from the saved output in one pass (csrc/gemm_split.hip: act_bwd_kernel)."""
+    """(g * act'(.), max |result| or None) from the saved output in one pass (csrc/gemm_split.hip: act_bwd_kernel)."""
     g = g.contiguous()
     if not (g.is_cuda and out.is_contiguous() and g.numel() % 4 == 0 and g.data_ptr() % 16 == 0):
         neg = out + 1.0 if act == ACT_ELU else torch.full_like(out, slope)
-        return g * torch.where(out > 0, torch.ones_like(out), neg)
+        return g * torch.where(out > 0, torch.ones_like(out), neg), None
     gin = torch.empty_like(g)
-    _lib.call("disgat_act_bwd", g.data_ptr(), out.data_ptr(), gin.data_ptr(), g.numel(), act, float(slope), ops._stream())
-    return gin
+    am = torch.empty(1, dtype=torch.float32, device=g.device)
+    _lib.call("disgat_act_bwd", g.data_ptr(), out.data_ptr(), gin.data_ptr(), g.numel(), act, float(slope), am.data_ptr(),
+              ops._stream())
+    return gin, am
 
 
 def _tn_ok(a, g, k, n):
@@ -181,15 +183,17 @@ class _Linear(torch.autograd.Function):
     def backward(ctx, g):
         a, w, out = ctx.saved_tensors
         act, slope, has_bias, has_init = ctx.meta
+        g_am = None
         if act != ACT_NONE:
-            g = _act_backward(g, out, act, slope)
+            g, g_am = _act_backward(g, out, act, slope)
         ga = gw = gb = gi = None
         # grad of the data operand: the same split-bf16 GEMM with the transposed weight (falls back to hipBLASLt
         # through _forward's own shape check); the weight gradient reduces over the million-row dimension and
         # stays on hipBLASLt.
         # one max |g| pass serves both GEMMs below
-        g_am = amax(g) if (mode() == "f16x3" and g.is_cuda and g.dim() == 2 and g.is_contiguous() and g.shape[1] % 4 == 0
-                           and g.data_ptr() % 16 == 0) else None
+        if g_am is None and (mode() == "f16x3" and g.is_cuda and g.dim() == 2 and g.is_contiguous() and g.shape[1] % 4 == 0
+                             and g.data_ptr() % 16 == 0):
+            g_am = amax(g)
         if a.dim() == 3:
             hb, m, k = a.shape
             g3 = g.view(m, hb, -1).permute(1, 0, 2)

@@ -187,9 +187,10 @@ int disgat_split_f16(const float* W, int64_t stride_b, int64_t stride_k, int64_t
                      uint16_t* planes, float* amax_scale, disgat_stream_t stream);
 
 /* Backward of the epilogue activation from the saved output (n contiguous floats, n % 4 == 0):
- * gin = g * (out > 0 ? 1 : (act == 1 ? out + 1 : slope)); act 1 = ELU, 2 = leaky ReLU.  gin may alias g. */
+ * gin = g * (out > 0 ? 1 : (act == 1 ? out + 1 : slope)); act 1 = ELU, 2 = leaky ReLU.  gin may alias g.
+ * amax_out (or NULL): receives max |gin|, the scale input of the GEMMs that consume gin. */
 int disgat_act_bwd(const float* g, const float* out, float* gin, int64_t n, int act, float slope,
-                   disgat_stream_t stream);
+                   float* amax_out, disgat_stream_t stream);
 
 #ifdef __cplusplus
 }
