@@ -308,24 +308,33 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void seg_grad_sign_kernel(const Si
     for (int mbase = mb; mbase < me; mbase += 64) {
       const int cnt = min(64, me - mbase);
       const int pv = (lane < cnt) ? (A.perm ? A.perm[mbase + lane] : mbase + lane) : 0;
-      for (int i = 0; i < cnt; i += 4) {          // 4 positions in flight; lanes >= cnt hold position 0 (valid memory)
-        uint32_t w[4];
-        float gv[4];
+      // groups of 4 positions, the next group's loads in flight while the current one is accumulated (2-deep);
+      // lanes >= cnt hold position 0 (valid memory), their gradient is masked
+      auto fetch = [&](uint32_t(&w)[4], float(&gv)[4], int i) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          const int64_t pos = __builtin_amdgcn_readlane(pv, i + t);
+          const int64_t pos = __builtin_amdgcn_readlane(pv, (i + t) & 63);
           w[t] = sg[pos * 64];
           gv[t] = (active && i + t < cnt) ? gh[pos] : 0.f;
         }
+      };
+      auto accum = [&](const uint32_t(&w)[4], const float(&gv)[4]) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           __builtin_amdgcn_sched_barrier(0);      // one position at a time: keeps the 32 bit->float temporaries from piling up
           gall += gv[t];
 #pragma unroll
-          for (int j = 0; j < QN; ++j) {
-            up[j] += gv[t] * sign_floats<QN>(w[t], j);      // shift, and, 4 v_cvt_f32_ubyteN, 2 v_pk_fma_f32
-          }
+          for (int j = 0; j < QN; ++j) up[j] += gv[t] * sign_floats<QN>(w[t], j);   // shift, and, 4 v_cvt_f32_ubyteN, 2 v_pk_fma_f32
         }
+      };
+      uint32_t wA[4], wB[4];
+      float gA[4], gB[4];
+      fetch(wA, gA, 0);
+      for (int i = 0; i < cnt; i += 8) {
+        if (i + 4 < cnt) fetch(wB, gB, i + 4);
+        accum(wA, gA);
+        if (i + 8 < cnt) fetch(wA, gA, i + 8);
+        if (i + 4 < cnt) accum(wB, gB);
       }
     }
     float* op = A.gkey + (size_t)key * A.ld_gkey + qoff;
