@@ -9,7 +9,8 @@ out of reach (hours):
     (two independent kernels, same formula);
   * the SAGE epilogue equals the AT aggregate / (1 + 1);
   * the backward's grad-x of sum(Z) equals the in-degree-weighted attention mass: sum over all
-    columns of grad x == number of non-empty rows * H (every row distributes total weight 1 per head).
+    columns of grad x == number of non-empty rows * H (every row distributes total weight 1 per head);
+  * the two att-3 score backwards (sign record / operand re-gather) agree on the edge list and on an aux list.
 """
 import pytest
 import torch
@@ -84,3 +85,32 @@ def test_fullsize_properties(name, n, e, f, att, monkeypatch):
         total = float(xg.grad.double().sum())
         want = float((deg > 0).sum()) * H * f
         assert abs(total - want) <= 1e-5 * want
+
+
+@pytest.mark.parametrize("name,n,e,f", SIZES)
+def test_fullsize_sign_backward_equals_gather_backward(name, n, e, f):
+    """att-3 score backward at full size, two independent implementations: from the forward's sign record
+    (seg_grad_sign_kernel, the default) and by re-gathering the operand rows (seg_grad_att3_kernel).  Same edge pass
+    and the same aux list (with a head range) feed both; gP, gQ and grad a must agree to fp32 summation noise."""
+    from edgedisentangle_ssl_amd import ops, synth
+    dev = torch.device("cuda")
+    H = 8
+    g = synth.powerlaw_graph(n, e, dev)
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    x = torch.randn(n, f, device=dev, generator=gen)
+    pairs, _ = synth.uniform_pairs(n, 3 * g.nnz // 2, dev)
+    we = torch.randn(H, g.nnz, device=dev, generator=gen) * 0.1
+    wa = torch.randn(H, pairs.shape[1], device=dev, generator=gen) * 0.1
+    grads = {}
+    for sign in (True, False):
+        rowop = (torch.randn(n, H * f, device=dev, generator=torch.Generator(device="cuda").manual_seed(1)) * 0.2).requires_grad_(True)
+        colop = (torch.randn(n, H * f, device=dev, generator=torch.Generator(device="cuda").manual_seed(2)) * 0.2).requires_grad_(True)
+        a = (torch.randn(H * f, device=dev, generator=torch.Generator(device="cuda").manual_seed(3)) * 0.05).requires_grad_(True)
+        z, ee, _ = ops.EdgePass.apply(x, rowop, colop, a, (g, 3, H, f, f, False, (0.0, 0), sign))
+        aux = ops.AuxPass.apply(None, rowop, colop, a, pairs, (3, H, f, f, n, 2, 7, sign))
+        loss = (ee * we).sum() + (aux[2:7] * wa[2:7]).sum() + z.sum() * 1e-3
+        grads[sign] = torch.autograd.grad(loss, [rowop, colop, a])
+        del z, ee, aux, loss, rowop, colop, a
+    for name_, gs, gg in zip(("gP", "gQ", "ga"), grads[True], grads[False]):
+        scale = float(gg.abs().max())
+        assert float((gs - gg).abs().max()) <= 2e-5 * scale, (name_, float((gs - gg).abs().max()), scale)
