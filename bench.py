@@ -316,6 +316,7 @@ def main():
         pass
     roof = None
     if agg:
+        gemm = {k: agg.pop(k) for k in list(agg) if k.startswith("gemm")}        # flop-counted launches (MFMA class)
         label, (b, sec, cnt) = max(agg.items(), key=lambda kv: kv[1][1])
         ach = b / sec / 1e9
         roof = {"bound": "hbm", "kernel": label, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -323,6 +324,9 @@ def main():
                 "avg_launch_ms": round(sec / cnt * 1e3, 3), "algorithmic_bytes_per_launch": int(b / cnt),
                 "all_kernels": {k: {"GB/s": round(v[0] / v[1] / 1e9, 1), "ms_total": round(v[1] * 1e3, 2), "launches": v[2]}
                                 for k, v in agg.items()}}
+        for k, v in gemm.items():       # fp32-equivalent rate of the dense contractions (x3 fp16 MFMA products inside)
+            roof["all_kernels"][k] = {"TFLOP/s_fp32_equiv": round(v[0] / v[1] / 1e12, 1), "ms_total": round(v[1] * 1e3, 2),
+                                      "launches": v[2]}
     cpu = None
     if not o.no_cpu_baseline and world == 1:          # rank 0, N=1 only (bench contract)
         cpu = cpu_baseline(o)
