@@ -96,6 +96,28 @@ class Trainer(object):
     def _layer_on(self, i):
         return self.constrain_layer == 0 or self.constrain_layer == i       # pretrainer.py:597, 728
 
+    def analyze_disentangle(self, feature, adj):
+        """trainer.py:82-134: how different are the heads?  Per layer: the head x head correlation of the raw scores
+        on a sampled pair list (a third of the edges + 3x as many random pairs), its mean absolute value, and the
+        feature-dimension correlation of the layer output.  The reference draws the pairs through dense N x N masks
+        and plots the grids; here the pairs come from the O(E) device sampler and the grids are returned."""
+        from .utils import group_correlation
+        assert self.args.model == "DISGAT", "analyze disentanglement is only implemented for DISGAT"
+        fusers = [self.fuse1, self.fuse2]
+        g = graph_of(adj)
+        with torch.no_grad():
+            feats = self.models[0].get_em(feature, adj, fusers)
+            indices, _ = sampling.sample_pairs(g.n, sampling.flat_edges(g))
+            scores = self.models[0].predict_adjs_sparse(feature, adj, fusers, auxiliary_edges=[indices])
+            at_cor, at_dist, feat_cor = [], [], []
+            for layer in range(2):
+                feat_cor.append(group_correlation(feats[layer].t()))
+                per_head = torch.stack([h[0][:, 0] for h in scores[layer]])            # [H, M]
+                cor = group_correlation(per_head)
+                at_cor.append(cor)
+                at_dist.append(torch.mean(torch.abs(cor)).item())
+        return at_dist, at_cor, feat_cor
+
 
 class SupEdgeTrainer(Trainer):
     """Edge-recovery supervision on the sum of all heads (pretrainer.py:658-776)."""

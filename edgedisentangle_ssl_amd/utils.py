@@ -87,3 +87,12 @@ def adj_mse_loss(adj_rec, adj_tgt):
 def accuracy(output, labels):
     preds = output.max(1)[1].type_as(labels)
     return preds.eq(labels).double().sum() / len(labels)
+
+
+def group_correlation(embedding):
+    """Pearson correlation between the rows of `embedding` [R, C] -> [R, R] (utils.py:326-334: each row centred by
+    its own mean, Gram matrix divided by the outer product of the row norms)."""
+    centred = embedding - embedding.mean(dim=-1, keepdim=True)
+    gram = centred @ centred.t()
+    norm = torch.sqrt(torch.diagonal(gram))
+    return gram / torch.outer(norm, norm)

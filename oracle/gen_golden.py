@@ -103,6 +103,10 @@ def gen_prims():
     ic.load_params(mlp, 80)
     out["mlp_raw"] = np32(mlp(feats[0]))
     out["mlp_cls"] = np32(mlp(feats[0], cls=True))
+    # utils.group_correlation (utils.py:326), used by Trainer.analyze_disentangle
+    emb = torch.from_numpy(g.standard_normal((7, 33)).astype(np.float32))
+    out["corr_in"] = np32(emb)
+    out["corr_out"] = np32(ref_utils.group_correlation(emb))
     np.savez_compressed(os.path.join(GOLD, "prims.npz"), **out)
     print("prims.npz", len(out))
     # initial parameters of the reference's DISGAT under torch.manual_seed(4) (RNG draw order contract)

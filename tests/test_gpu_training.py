@@ -25,3 +25,28 @@ def test_main_flow_trains(golden_dir, gnn, att):
     # the optimisers really step through the fused backward: the training losses move down
     assert hist[-1]["loss_head_diversity"] < hist[0]["loss_head_diversity"]
     assert hist[-1]["loss_train"] < hist[0]["loss_train"]
+
+
+def test_analyze_disentangle_returns_correlation_grids(golden_dir):
+    """Trainer.analyze_disentangle (trainer.py:82-134) on the HIP path: per layer a head x head score correlation,
+    its mean absolute value and a feature-dimension correlation of the layer output."""
+    import inputs_common as ic
+    from test_gpu_parity import build, real_inputs
+    from edgedisentangle_ssl_amd import pretrainer
+    dev = torch.device("cuda")
+    x, adj, n, ei, sup, ho, he = real_inputs(golden_dir, "chameleon", dev)
+    a, enc, fus = build("AT", 3, 4, 32, x.shape[1], 321, dev)
+    a.lr, a.weight_decay, a.dis_type = 0.01, 5e-4, 1
+    tr = pretrainer.SupEdgeTrainer(a, enc, 1.0)
+    ic.load_params(tr.fuse1, 7)
+    ic.load_params(tr.fuse2, 8)
+    for m in tr.models:
+        m.to(dev).eval()
+    dist, at_cor, feat_cor = tr.analyze_disentangle(x, adj)
+    assert len(dist) == len(at_cor) == len(feat_cor) == 2
+    for layer in range(2):
+        c = at_cor[layer]
+        assert c.shape == (4, 4) and torch.allclose(c, c.t(), atol=1e-5)
+        assert torch.allclose(torch.diagonal(c), torch.ones(4, device=dev), atol=1e-4)
+        assert 0.0 < dist[layer] <= 1.0 + 1e-6
+        assert feat_cor[layer].shape == (32, 32) and torch.isfinite(feat_cor[layer]).all()

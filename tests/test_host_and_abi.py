@@ -190,3 +190,11 @@ def test_same_seed_gives_the_reference_initial_parameters(golden_dir):
             assert keys == list(sd.keys())
             for k in keys:
                 assert np.array_equal(sd[k].numpy(), g[f"{gnn}_{att}.{k}"]), (gnn, att, k)
+
+
+def test_group_correlation_matches_reference(golden_dir):
+    import os
+    from edgedisentangle_ssl_amd.utils import group_correlation
+    g = np.load(os.path.join(golden_dir, "prims.npz"))
+    got = group_correlation(torch.from_numpy(g["corr_in"]))
+    assert np.allclose(got.numpy(), g["corr_out"], atol=2e-6)
