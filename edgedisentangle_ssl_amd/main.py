@@ -4,6 +4,7 @@
 Extra flags (not in the reference): --data_root (directory holding <dataset>/ in the reference's
 format) or --fixture (a tests/golden/data_<name>.npz file), --quiet.
 """
+import os
 import random
 import sys
 import time
@@ -16,6 +17,29 @@ from .features import surrogate_features
 from .utils import get_parser
 
 SSL = {"DisEdge": pretrainer.GeneratedEdgeTrainer, "SupEdge": pretrainer.SupEdgeTrainer, "DifHead": pretrainer.DifHeadTrainer}
+
+
+def checkpoint_path(args, epoch, root="."):
+    """The reference's checkpoint location (main.py:218, 230): one file per (pretrain list, epoch)."""
+    folder = "{}/checkpoint/{}/{}_used_edge{}_weight{}_reg{}".format(root, args.dataset, args.model, args.used_edge,
+                                                                   args.pre_weight, args.reg)
+    return folder, "{}/pretrain_{}_{}.pth".format(folder, args.pretrain, epoch)
+
+
+def save_model(encoder, args, epoch, root="."):
+    """main.py:214-227: {'encoder': state_dict} - the keys are the reference's, so either side loads the other's file."""
+    folder, path = checkpoint_path(args, epoch, root)
+    os.makedirs(folder, exist_ok=True)
+    torch.save({"encoder": encoder.state_dict()}, path)
+    return path
+
+
+def load_model(encoder, args, root="."):
+    """main.py:229-235: restore the encoder saved at epoch `--load` under the same settings."""
+    _, path = checkpoint_path(args, args.load, root)
+    content = torch.load(path, map_location=lambda storage, loc: storage)
+    encoder.load_state_dict(content["encoder"])
+    return path
 
 
 def run(argv=None, log=print):
@@ -61,6 +85,8 @@ def run(argv=None, log=print):
     # SupEdge / DisEdge only read the aux scores of predict_adjs_sparse: skip the layer-2 aggregation + fuser the
     # reference computes and discards there (same losses and gradients, ~12 % less work per SSL step)
     encoder.skip_unused = True
+    if args.load is not None:                                             # main.py:262-263
+        load_model(encoder, args)
     ssl_trainers, ssl_labels = [], []
     for i, name in enumerate(args.pretrain or []):                        # main.py:242-251
         assert args.pre_edge[i] > 0, "edge index begins from 1"

@@ -198,3 +198,21 @@ def test_group_correlation_matches_reference(golden_dir):
     g = np.load(os.path.join(golden_dir, "prims.npz"))
     got = group_correlation(torch.from_numpy(g["corr_in"]))
     assert np.allclose(got.numpy(), g["corr_out"], atol=2e-6)
+
+
+def test_checkpoint_round_trip_uses_the_reference_layout(tmp_path):
+    """main.save_model / load_model (main.py:214-235): {'encoder': state_dict} under the reference's path scheme."""
+    from types import SimpleNamespace
+    from edgedisentangle_ssl_amd import DISGAT, main
+    a = SimpleNamespace(gnn_type="AT", att=3, residue=False, residue_type=0, fuse_no_relu=False, dataset="cora", model="DISGAT",
+                        used_edge=1, pre_weight=[1.0, 1.0], reg=False, pretrain=["SupEdge", "DifHead"], load=7)
+    torch.manual_seed(1)
+    m1 = DISGAT(a, nfeat=20, nhid=12, nclass=12, nheads=3, dropout=0.1)
+    path = main.save_model(m1, a, 7, root=str(tmp_path))
+    assert path.endswith("checkpoint/cora/DISGAT_used_edge1_weight[1.0, 1.0]_regFalse/pretrain_['SupEdge', 'DifHead']_7.pth")
+    assert list(torch.load(path).keys()) == ["encoder"]
+    torch.manual_seed(2)
+    m2 = DISGAT(a, nfeat=20, nhid=12, nclass=12, nheads=3, dropout=0.1)
+    main.load_model(m2, a, root=str(tmp_path))
+    for (k1, v1), (k2, v2) in zip(m1.state_dict().items(), m2.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2)
