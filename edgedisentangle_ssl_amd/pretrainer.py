@@ -31,6 +31,40 @@ def make_adam(params, args):
     return optim.Adam(params, lr=args.lr, weight_decay=args.weight_decay, **({"fused": True} if fused else {}))
 
 
+def _pair_loss_value(base, h_lo, h_hi, labels, graph):
+    """(loss, neg_w, m) from the HIP partial sums; on a sharded graph sums and pair count are all-reduced (global loss)."""
+    acc = ops.pair_loss_sums(base, h_lo, h_hi, labels)
+    acc = torch.cat([acc, acc.new_full((1,), float(labels.shape[0]))])     # fill kernel: stays graph-capturable
+    parallel.all_reduce_sum(acc, graph)
+    m = acc[3]
+    neg_w = acc[2] / (m * m - acc[2])
+    return ((acc[0] + neg_w * acc[1]) / m).to(torch.float32), neg_w, m
+
+
+class _PairLoss(torch.autograd.Function):
+    """Differentiable weighted-MSE pair loss on the [H,M] score buffer: forward = the partial-sum kernel, backward =
+    one kernel writing d loss / d score for every row (the torch formulation took ~10 passes over [M] / [H,M]
+    temporaries per loss).  Sharded: the value is the global loss, the gradient this rank's part (global weights)."""
+
+    @staticmethod
+    def forward(ctx, base, labels, h_lo, h_hi, graph):
+        loss, neg_w, m = _pair_loss_value(base, h_lo, h_hi, labels, graph)
+        ctx.save_for_backward(base, labels, neg_w, m)
+        ctx.rng = (h_lo, h_hi)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        base, labels, neg_w, m = ctx.saved_tensors
+        h_lo, h_hi = ctx.rng
+        coef = (torch.stack([torch.ones_like(neg_w), neg_w]) * (gout.double() / m)).to(torch.float32).contiguous()
+        g = torch.empty_like(base)
+        from . import _lib
+        _lib.call("disgat_pair_loss_bwd", base.data_ptr(), int(base.shape[1]), int(base.shape[0]), h_lo, h_hi,
+                  labels.data_ptr(), coef.data_ptr(), g.data_ptr(), ops._stream())
+        return g, None, None, None, None
+
+
 def pair_mse_loss(aux, h_lo, h_hi, labels, graph=None):
     """pred = sigmoid(sum_{h in [lo,hi)} aux_h); utils.adj_mse_loss(pred, labels) on 1-D input
     (pretrainer.py:734-739, 619-627).  aux: list of H [M,1] tensors (entries outside the range may
@@ -41,17 +75,11 @@ def pair_mse_loss(aux, h_lo, h_hi, labels, graph=None):
     sharded = isinstance(graph, parallel.DistGraph) and graph.world > 1
     fused = (base is not None and base.dim() == 2 and base.is_contiguous() and base.shape[1] == labels.shape[0]
              and heads[0].data_ptr() == base[h_lo].data_ptr())
-    if fused and not (torch.is_grad_enabled() and any(h.requires_grad for h in heads)):
-        acc = ops.pair_loss_sums(base, h_lo, h_hi, labels)
-        acc = torch.cat([acc, acc.new_full((1,), float(labels.shape[0]))])     # fill kernel: stays graph-capturable
-        parallel.all_reduce_sum(acc, graph)
-        m = acc[3]
-        neg_w = acc[2] / (m * m - acc[2])
-        return ((acc[0] + neg_w * acc[1]) / m).to(torch.float32)
-    if fused:       # the heads are rows of one [H,M] score buffer: sum the rows in place (no stack, one gradient slice)
-        pred = torch.sigmoid(base[h_lo:h_hi].sum(0))
-    else:
-        pred = torch.sigmoid(torch.sum(torch.stack(heads), dim=0)).squeeze(-1)
+    if fused and labels.dtype == torch.float32 and labels.is_contiguous():
+        if torch.is_grad_enabled() and base.requires_grad:
+            return _PairLoss.apply(base, labels, h_lo, h_hi, graph)
+        return _pair_loss_value(base, h_lo, h_hi, labels, graph)[0]
+    pred = torch.sigmoid(torch.sum(torch.stack(heads), dim=0)).squeeze(-1)
     if not sharded:
         return adj_mse_loss(pred, labels)
     # sharded + autograd: class weights and the mean use GLOBAL counts; this rank contributes the

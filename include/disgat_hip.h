@@ -106,6 +106,11 @@ int disgat_pair_loss(const float* aux, int64_t M, int h_lo, int h_hi, const floa
 
 /* ---- backward -------------------------------------------------------------------------- */
 
+/* Gradient of that loss w.r.t. the raw scores: g[h][m] = coef[labels[m] != 0 ? 0 : 1] * 2 (p - t) p (1 - p) for h in
+ * [h_lo, h_hi), 0 for the other of the H rows; coef = 2 device floats (upstream gradient x class weight / M). */
+int disgat_pair_loss_bwd(const float* aux, int64_t M, int H, int h_lo, int h_hi, const float* labels,
+                         const float* coef, float* g, disgat_stream_t stream);
+
 /* Per edge and head: ge_out = ge_in + d(loss)/d(e) through softmax-of-sigmoid given gZ (grad of Z),
  * and beta = alpha*sc, the coefficient of x[col] in Z (used by the transposed pass for grad x).
  * ge_in may be NULL.  Items/col as in disgat_edge_fwd; Z, den, edge_e are the forward's outputs. */
