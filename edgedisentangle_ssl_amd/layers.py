@@ -148,8 +148,9 @@ def _memo(layers, tag, build):
     graph: inference repeats the same ~40 small packing kernels per layer otherwise, which is most of a small graph's
     latency.  Keyed on every parameter's identity, storage and version, so any update rebuilds; one entry per tag."""
     params = [p for l in layers for p in l.parameters()]
-    if torch.is_grad_enabled() and any(p.requires_grad for p in params):
-        return build()
+    if layers[0].training or (torch.is_grad_enabled() and any(p.requires_grad for p in params)):
+        return build()          # only eval-mode, graph-free forwards reuse (writes through `param.data` do not bump
+                                # the version counter: call layers.clear_weight_cache(module) after such an edit)
     key = tuple((id(p), p.data_ptr(), p._version) for p in params)
     cache = layers[0].__dict__.setdefault("_disgat_memo", {})
     hit = cache.get(tag)
@@ -158,6 +159,13 @@ def _memo(layers, tag, build):
     val = build()
     cache[tag] = (key, val)
     return val
+
+
+def clear_weight_cache(module):
+    """Drop the packed-weight caches of every layer under `module` (needed only after editing parameters through
+    `.data`, which the cache key cannot see)."""
+    for m in module.modules():
+        m.__dict__.pop("_disgat_memo", None)
 
 
 def _pack_score_operands(layers, x, x_all, att, H, Hp, f_in, f_out, fp, am=None):
