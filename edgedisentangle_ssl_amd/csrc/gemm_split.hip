@@ -823,7 +823,7 @@ __global__ __launch_bounds__(256) void wamax_kernel(const float* __restrict__ W,
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
-  if ((threadIdx.x & 63) == 0 && m != 0u) atomicMax(out, m);
+  if ((threadIdx.x & 63) == 0 && m > __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out, m);   // most waves find a larger value already there: tens of atomics, not tens of thousands
 }
 
 __global__ __launch_bounds__(256) void wsplit_kernel(const float* __restrict__ W, int64_t sb, int64_t sk, int64_t sn, int K,
@@ -870,7 +870,7 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ A, 
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
-  if ((threadIdx.x & 63) == 0 && m != 0u) atomicMax(out, m);
+  if ((threadIdx.x & 63) == 0 && m > __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out, m);   // most waves find a larger value already there: tens of atomics, not tens of thousands
 }
 
 }  // namespace disgat
@@ -898,7 +898,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
   if (amax_out != nullptr) {          // max |gin| for the GEMMs that consume it (saves them a pass over gin)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
-    if ((threadIdx.x & 63) == 0 && m != 0u) atomicMax(amax_out, m);
+    if ((threadIdx.x & 63) == 0 && m > __hip_atomic_load(amax_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(amax_out, m);
   }
 }
 }  // namespace disgat
