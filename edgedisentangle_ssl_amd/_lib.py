@@ -97,7 +97,7 @@ _SIGS = {
     "disgat_seg_grad_att3": (_c.c_int, [_P, _c.c_int, _P, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
                                         _P, _c.c_int, _P, _c.c_int, _P, _P, _c.c_int, _P, _c.c_int, _P]),
     "disgat_seg_grad_sign": (_c.c_int, [_P, _c.c_int, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P,
-                                        _P, _c.c_int, _P, _P, _c.c_int, _P, _c.c_int, _P]),
+                                        _P, _c.c_int, _P, _P, _c.c_int, _P, _c.c_int, _c.c_int, _P]),
     "disgat_seg_grad_hx": (_c.c_int, [_c.c_int, _P, _c.c_int, _P, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int,
                                       _c.c_int, _P, _c.c_int, _P, _c.c_int, _c.c_int, _P]),
     "disgat_gemm_split": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _P, _P, _P, _c.c_int64, _c.c_int64, _P, _c.c_int64,

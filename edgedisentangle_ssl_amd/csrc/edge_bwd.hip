@@ -277,6 +277,7 @@ struct SignArgs {
   float* gkey;
   int ld_gkey;
   float* ga_part;        // [n_waves][H*FQ] or null
+  int accumulate;        // 1: add into gkey (heads outside [h_lo, h_hi) are left untouched) instead of storing
 };
 
 template <int HL, int QN>
@@ -344,7 +345,7 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void seg_grad_sign_kernel(const Si
     for (int j = 0; j < QN; ++j) {           // a (8 KB, cache-resident) and the key's operand row are read here, once per item
       const f32x4 u = 0.99f * up[j] + base;
       if (want_ga) ga[j] += ld4(pp + j * G * 4) * u;
-      out4(op + j * G * 4, ld4(A.a + qoff + j * G * 4) * u, slot >= 0, false);
+      if (!A.accumulate || active) out4(op + j * G * 4, ld4(A.a + qoff + j * G * 4) * u, slot >= 0, A.accumulate != 0);
     }
   }
   if (want_ga) {
@@ -553,7 +554,7 @@ extern "C" int disgat_seg_grad_att3(const int32_t* items, int n_items, const int
 extern "C" int disgat_seg_grad_sign(const int32_t* items, int n_items, const int32_t* perm, const float* g,
                                     int64_t g_stride, int h_lo, int h_hi, int H, int F_out, const uint32_t* sign_bits,
                                     const float* keyop, int ld_key, const float* a, float* gkey, int ld_gkey,
-                                    float* ga_part, int n_waves, disgat_stream_t stream) {
+                                    float* ga_part, int n_waves, int accumulate, disgat_stream_t stream) {
   using namespace disgat;
   if (n_items == 0) return 0;
   const int hl = ilog2_exact(H);
@@ -568,7 +569,7 @@ extern "C" int disgat_seg_grad_sign(const int32_t* items, int n_items, const int
   DISGAT_REQUIRE(n_waves > 0 && n_waves % DISGAT_WAVES_PER_BLOCK == 0, "seg_grad_sign: n_waves must be a positive multiple of %d", DISGAT_WAVES_PER_BLOCK);
   const int qn = F_out / g4;
   SignArgs A{reinterpret_cast<const int4*>(items), n_items, perm, g, g_stride, h_lo, h_hi, sign_bits, keyop, ld_key, a,
-             gkey, ld_gkey, ga_part};
+             gkey, ld_gkey, ga_part, accumulate};
   const dim3 grid(n_waves / DISGAT_WAVES_PER_BLOCK), block(DISGAT_BLOCK);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 #define DISGAT_SS(HL_, QN_) hipLaunchKernelGGL((seg_grad_sign_kernel<HL_, QN_>), grid, block, 0, s, A)

@@ -262,12 +262,23 @@ def disga_heads(layers, x, adj, aux_indices=None, head_ranges=None, aux_only=Fal
         return r, c, av, d
 
     rec = ops.wants_sign(att, rowop, colop, a_vec)     # att 3: record lrelu signs for a gather-free backward
+    if aux_indices is not None and not isinstance(aux_indices, list):
+        aux_indices = [aux_indices]
+    # differentiable att-3 layer with aux lists, one head group, no column slices (the training configuration): the edge
+    # pass and all aux lists form ONE autograd node, so P / Q / a get one gradient each (ops.LayerPass)
+    merged_aux = None
+    merge = rec and not aux_only and aux_indices and n_groups == 1 and f_in_p <= tile
     heads = e_list = None
     if not aux_only:
         z_groups, e_groups = [], []
         for gi in range(n_groups):
             r, c, av, d = group_ops(gi)
-            if f_in_p <= tile:
+            if merge:
+                ranges = tuple((0, H) if head_ranges is None or head_ranges[li] is None else tuple(head_ranges[li])
+                               for li in range(len(aux_indices)))
+                cfg = (graph, att, Hk, f_in_p, fp, gnn == "SAGE", d, ranges)
+                z, edge_e, _den, *merged_aux = ops.LayerPass.apply(xg, r, c, av, cfg, *aux_indices)
+            elif f_in_p <= tile:
                 cfg = (graph, att, Hk, f_in_p, fp, gnn == "SAGE", d, rec)
                 z, edge_e, _den = ops.EdgePass.apply(xg, r, c, av, cfg)
             else:
@@ -319,12 +330,15 @@ def disga_heads(layers, x, adj, aux_indices=None, head_ranges=None, aux_only=Fal
 
     aux_out = None
     if aux_indices is not None:
-        if not isinstance(aux_indices, list):
-            aux_indices = [aux_indices]
         per_list = []
         for li, pairs in enumerate(aux_indices):
             lo, hi = (0, H) if head_ranges is None or head_ranges[li] is None else head_ranges[li]
             per_head = [None] * H
+            if merged_aux is not None:
+                for h in range(lo, hi):
+                    per_head[h] = merged_aux[li][h].unsqueeze(1)
+                per_list.append(per_head)
+                continue
             for gi in range(n_groups):
                 g_lo, g_hi = max(lo, gi * Hk), min(hi, (gi + 1) * Hk)      # heads of this group that are scored
                 if g_lo >= g_hi:

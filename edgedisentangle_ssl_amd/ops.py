@@ -178,3 +178,32 @@ class AuxPass(torch.autograd.Function):
     def backward(ctx, gout):
         from . import ops_bwd
         return ops_bwd.aux_backward(ctx, gout)
+
+
+class LayerPass(torch.autograd.Function):
+    """Edge pass + every aux list of one att-3 layer as ONE autograd node (differentiable forwards with a sign
+    record): the score operands P, Q and `a` then receive one gradient each, accumulated list after list inside the
+    backward kernels, instead of one full [N, H*F_out] tensor per consumer summed by autograd.
+    cfg = (graph, att, H, F_in, F_out, sage, drop, ranges) with ranges[i] = (h_lo, h_hi) of aux list i."""
+
+    @staticmethod
+    def forward(ctx, x, rowop, colop, a, cfg, *lists):
+        graph, att, H, F_in, F_out, sage, drop, ranges = cfg
+        ctx.sign = sign_record(att, H, F_out, graph.nnz, x.device) if graph.nnz else None
+        z, edge_e, den = edge_forward(graph, att, H, F_in, F_out, x, rowop, colop, a, sage, drop, sign=ctx.sign)
+        outs, ctx.aux_signs = [], []
+        for pairs, (lo, hi) in zip(lists, ranges):
+            m = int(pairs.shape[1])
+            sg = sign_record(att, H, F_out, m, pairs.device) if m else None
+            outs.append(aux_forward(att, H, F_in, F_out, pairs, graph.n, None, rowop, colop, a, lo, hi, sign=sg))
+            ctx.aux_signs.append(sg)
+        ctx.cfg = cfg
+        ctx.save_for_backward(x, rowop, colop, a, z, edge_e, den, *lists)
+        ctx.mark_non_differentiable(den)
+        ctx.set_materialize_grads(False)      # outputs nobody differentiates arrive as None, and their passes are skipped
+        return (z, edge_e, den, *outs)
+
+    @staticmethod
+    def backward(ctx, gz, ge, _gden, *gaux):
+        from . import ops_bwd
+        return ops_bwd.layer_backward(ctx, gz, ge, gaux)

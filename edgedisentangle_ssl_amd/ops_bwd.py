@@ -33,16 +33,16 @@ def _seg_att3(wi, other, perm, g, lo, hi, H, f_out, keyop, otherop, a, n_keys, w
     return gkey, (ga_part.sum(0) if want_ga else None)
 
 
-def _seg_sign(wi, perm, g, lo, hi, H, f_out, sign, keyop, a, n_keys, want_ga):
+def _seg_sign(wi, perm, g, lo, hi, H, f_out, sign, keyop, a, n_keys, want_ga, into=None):
     """Score backward of one side (rows: keyop = P, columns: keyop = Q) from the forward's sign record.
-    Returns (gkey [n_keys, H*f_out], this side's share of grad a or None)."""
+    Returns (gkey [n_keys, H*f_out], this side's share of grad a or None); `into`: an existing gkey to add into."""
     dev = g.device
-    gkey = _keybuf((n_keys, H * f_out), dev, wi)
+    gkey = _keybuf((n_keys, H * f_out), dev, wi) if into is None else into
     n_waves = min(_MAX_WAVES, (wi.n_items + 3) // 4 * 4)
     ga_part = torch.empty((n_waves, H * f_out), dtype=torch.float32, device=dev) if want_ga else None
     _lib.call("disgat_seg_grad_sign", wi.items.data_ptr(), wi.n_items, ops._ptr(perm), g.data_ptr(), g.stride(0), lo, hi,
               H, f_out, sign.data_ptr(), keyop.data_ptr(), keyop.stride(0), a.data_ptr(), gkey.data_ptr(), gkey.stride(0),
-              ops._ptr(ga_part), n_waves, ops._stream())
+              ops._ptr(ga_part), n_waves, int(into is not None), ops._stream())
     return gkey, (ga_part.sum(0) if want_ga else None)
 
 
@@ -185,3 +185,34 @@ def aux_backward(ctx, gout):
             g_x = _keybuf(tuple(x.shape), dev, wi, x.stride(0) != f_in)
             _seg_hx(1, wi, other, perm32, gout, lo, hi, H, f_in, rowop, g_x, False)
     return g_x, g_row, g_col, g_a, None, None
+
+
+def layer_backward(ctx, gz, ge, gaux):
+    """Backward of ops.LayerPass: the edge list first (stores the operand gradients), then every aux list ADDS its
+    share into the same buffers inside seg_grad_sign_kernel."""
+    from types import SimpleNamespace
+    x, rowop, colop, a, z, edge_e, den, *lists = ctx.saved_tensors
+    graph, att, H, f_in, f_out, sage, drop, ranges = ctx.cfg
+    need_x, need_row, need_col, need_a = ctx.needs_input_grad[:4]
+    g_x = g_row = g_col = g_a = None
+    if (gz is not None or ge is not None) and graph.nnz:
+        ectx = SimpleNamespace(saved_tensors=(x, rowop, colop, a, z, edge_e, den), cfg=(graph, att, H, f_in, f_out, sage, drop),
+                               needs_input_grad=ctx.needs_input_grad, sign=ctx.sign)
+        g_x, g_row, g_col, g_a, _ = edge_backward(ectx, gz, ge)
+    chunk = ops.CHUNK[att]
+    n_rows, n_cols = rowop.shape[0], colop.shape[0]
+    for pairs, (lo, hi), sign, gout in zip(lists, ranges, ctx.aux_signs, gaux):
+        if gout is None or sign is None:
+            continue
+        gout = gout.contiguous()
+        if need_row or need_a:
+            wi, _perm, perm32 = _segments_of(pairs, 0, n_rows, chunk)
+            g_row, ga = _seg_sign(wi, perm32, gout, lo, hi, H, f_out, sign, rowop, a, n_rows, need_a, into=g_row)
+            if need_a:
+                g_a = ga if g_a is None else g_a + ga
+        if need_col or need_a:
+            wi, _perm, perm32 = _segments_of(pairs, 1, n_cols, chunk)
+            g_col, ga = _seg_sign(wi, perm32, gout, lo, hi, H, f_out, sign, colop, a, n_cols, need_a, into=g_col)
+            if need_a:
+                g_a = ga if g_a is None else g_a + ga
+    return (g_x, g_row if need_row else None, g_col if need_col else None, g_a if need_a else None, None) + (None,) * len(lists)

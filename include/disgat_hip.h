@@ -135,11 +135,13 @@ int disgat_seg_grad_att3(const int32_t* items, int n_items, const int32_t* other
  *   u[key] = sum_m g_m * (bit ? 1 : 0.01),  gkey[key] = a (.) u[key]  (atomic add into host-zeroed rows when
  *   slot >= 0),  ga_part[wave] = per-wave partial of sum_key keyop[key] (.) u[key]  (NULL: not wanted).
  * The a-gradient of a list is the sum of the row-side pass (keyop = P) and the column-side pass (keyop = Q),
- * because lrelu(z) = lrelu'(z) * (P + Q).  Reads 64 words + H floats per list position. */
+ * because lrelu(z) = lrelu'(z) * (P + Q).  Reads 64 words + H floats per list position.
+ * accumulate = 1 adds into gkey instead (several lists scoring against the same operands share one gradient buffer;
+ * columns of heads outside [h_lo, h_hi) are then left untouched). */
 int disgat_seg_grad_sign(const int32_t* items, int n_items, const int32_t* perm, const float* g,
                          int64_t g_stride, int h_lo, int h_hi, int H, int F_out, const uint32_t* sign_bits,
                          const float* keyop, int ld_key, const float* a, float* gkey, int ld_gkey,
-                         float* ga_part, int n_waves, disgat_stream_t stream);
+                         float* ga_part, int n_waves, int accumulate, disgat_stream_t stream);
 
 /* col_mode = 0: gkey[key][h][:] = sum_m coef[h][perm(m)] * otherop[other_m][:]          (F floats per row)
  * col_mode = 1: gkey[key][:] (+)= sum_m sum_h coef[h][perm(m)] * otherop[other_m][h][:]  (otherop rows H*F) */
