@@ -18,12 +18,14 @@ ap.add_argument("--feat", type=int, default=256)
 ap.add_argument("--att", type=int, default=3)
 ap.add_argument("--gnn_type", default="AT")
 ap.add_argument("--dropout", type=float, default=0.1)
+ap.add_argument("--skip-unused", action="store_true", help="DISGAT.skip_unused as main.run sets it (no discarded layer-2 aggregation)")
 a = ap.parse_args()
 sys.argv = ["bench.py", "--nodes", str(a.nodes), "--edges", str(a.edges), "--feat", str(a.feat), "--att", str(a.att),
             "--gnn_type", a.gnn_type]
 o = bench.parse()
 dev = torch.device("cuda")
 args, enc, (sup, dis, dif), graph, x, lists = bench.build_workload(o, 0, 1, dev)
+enc.skip_unused = a.skip_unused
 for m in list(enc.modules()):
     if hasattr(m, "dropout"):
         m.dropout = a.dropout
