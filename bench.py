@@ -7,12 +7,20 @@ on the homo / hetero lists + loss] + [DifHead: get_edge_em + MLP + NLL] - each w
 dropout 0, pre-sampled pair lists resident in HBM, CSR preprocessing outside the timed region.
 value = E_nnz (summed over ranks) / time per step.
 
-  python bench.py [--gpus N --steps K --warmup W]          (N>1: launched by torch.distributed.run)
+  python bench.py [--gpus N --steps K --warmup W] [--scaling weak|strong]
+
+N > 1: one rank per GPU over RCCL.  Under torch.distributed.run (RANK / WORLD_SIZE in the environment) this process
+IS a rank; started bare (`python bench.py --gpus N`) it first starts N rank processes itself - before anything in it
+touches the GPU - relays rank 0's JSON line and exits with the ranks' status.
 
 N = 1 workload: BASELINE configs[3]'s graph on one GPU (the size north_star's single-GPU target is
 quoted on): synthetic power-law, 1M nodes / 20M edges, 256-dim, 8 heads, att 3, gnn_type AT.
-N > 1: weak scaling - every rank owns 1M rows / ~20M entries of an N-times larger graph (N = 8 is
-configs[4]'s 8M nodes / 160M edges), one all-gather of the layer input per layer over RCCL.
+N > 1, --scaling weak (default): every rank owns 1M rows / ~20M entries of an N-times larger graph (N = 8 is
+configs[4]'s 8M nodes / 160M edges; pass --gnn_type GCN for its layer type), one all-gather of the layer input per
+layer over RCCL.  --scaling strong: the SAME 1M / 20M graph cut into N nnz-balanced row ranges (N = 4 is
+configs[3]'s "sharded across 4 MI355X").
+DISGAT_BENCH_REHEARSAL=1 puts every rank on cuda:0 over gloo (a one-GPU box): a functional rehearsal of the
+N-rank path, flagged in the output line, not a scaling measurement.
 """
 import argparse
 import json
@@ -44,6 +52,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-nodes", type=int, default=2048)
     ap.add_argument("--fwd-only", action="store_true", help="time one get_em (T_fwd) instead of T_iter")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="N>1: weak = 1M rows per rank of an N-times larger graph; strong = the same graph cut in N")
     ap.add_argument("--skip-unused", action="store_true",
                     help="secondary number: drop the layer-2 aggregation + fuser that predict_adjs_sparse computes and "
                          "discards (DISGAT.skip_unused); NOT the headline definition")
@@ -132,6 +142,22 @@ def build_workload(o, rank, world, dev):
         del idx, r, c
         labels = synth.node_labels(o.nodes, dev)
         lists = synth.ssl_lists(graph, labels)
+    elif o.scaling == "strong":
+        # configs[3]: the SAME graph, features and pair lists as the N = 1 workload, cut into `world` nnz-balanced
+        # row ranges (every rank regenerates the seeded global inputs and keeps its own rows / pairs)
+        from edgedisentangle_ssl_amd.parallel import DistGraph
+        full = synth.powerlaw_graph(o.nodes, o.edges, dev)
+        labels = synth.node_labels(o.nodes, dev)
+        glists = synth.ssl_lists(full, labels)
+        graph = DistGraph.shard(full, rank, world)
+        lo, hi = graph.row_start, graph.row_start + graph.n
+
+        def mine(idx, lab):
+            keep = (idx[0] >= lo) & (idx[0] < hi)
+            return torch.stack([idx[0][keep] - lo, idx[1][keep]]).contiguous(), lab[keep].contiguous()
+        lists = tuple(mine(i, l) for i, l in glists)
+        x = synth.features(o.nodes, o.feat, "cpu")[lo:hi].contiguous().to(dev)
+        del full, glists
     else:
         graph = sharded_graph(o, rank, world, dev)
         n_glob = graph.n_global
@@ -146,7 +172,8 @@ def build_workload(o, rank, world, dev):
             rows = torch.div(flat, n_glob, rounding_mode="floor")
             return torch.stack([rows, flat - rows * n_glob]), sampling.membership(flat, posset)
         lists = (pairs(m_sup, pos), pairs(m_sup // 4, pos[same]), pairs(m_sup - m_sup // 4, pos[~same]))
-    x = synth.features(o.nodes, o.feat, dev, seed=rank)
+    if not (world > 1 and o.scaling == "strong"):
+        x = synth.features(o.nodes, o.feat, dev, seed=rank)
     graph.work_items(ops.CHUNK[o.att])        # CSR preprocessing (work items): untimed, reported separately
     graph.prep_ms = prep_ms
     return a, enc, (sup, dis, dif), graph, x, lists
@@ -242,12 +269,46 @@ def cpu_baseline(o):
                       f"gnn={o.gnn_type}, T_iter {dt:.2f}s, " + (f"mean of {reps} run(s) after 1 warm-up" if reps else "single cold run")}
 
 
+def launch_ranks(o):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks as child processes of this one, which
+    has not touched the GPU (no HIP call, no torch.cuda.is_available(); nothing is exec'ed over an initialised
+    process), relay rank 0's JSON line and return the ranks' worst exit status."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(o.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(o.gpus), LOCAL_WORLD_SIZE=str(o.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "4")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True))
+    out, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        try:
+            rc = max(rc, abs(p.wait(timeout=120 if rc == 0 else 5)))
+        except subprocess.TimeoutExpired:       # a rank outlived rank 0 (rank 0 failed before a collective): end it
+            p.kill()
+            p.wait()
+            rc = rc or 1
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    return rc
+
+
 def main():
     o = parse()
+    if o.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(o))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != o.gpus and world > 1:
+    if world != o.gpus:
         raise SystemExit(f"--gpus {o.gpus} but WORLD_SIZE={world}")
     import torch.distributed as dist
     # rehearsal on a one-GPU box: DISGAT_BENCH_REHEARSAL=1 puts every rank on cuda:0 over gloo
@@ -256,11 +317,16 @@ def main():
         local = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if not rehearsal and torch.cuda.device_count() < world:
+            raise SystemExit(f"--gpus {world} needs {world} visible GPUs (found {torch.cuda.device_count()}); "
+                             "DISGAT_BENCH_REHEARSAL=1 rehearses the N-rank path on one GPU over gloo")
         torch.cuda.set_device(local)
         if rehearsal:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        world = dist.get_world_size()           # what the line reports comes from the process group, not the flag
+        rank = dist.get_rank()
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
@@ -335,19 +401,32 @@ def main():
     what = "T_fwd(get_em)" if o.fwd_only else "T_iter(SupEdge+DisEdge+DifHead fwd+loss)"
     if o.skip_unused and not o.fwd_only:
         what += " with the discarded layer-2 aggregation of predict_adjs_sparse skipped (secondary definition)"
+    strong = world > 1 and o.scaling == "strong"
+    if world == 1:
+        shape = f"synthetic power-law {o.nodes} nodes, nnz {int(nnz_total)}; BASELINE configs[3] graph on 1 GPU"
+    elif strong:
+        shape = (f"synthetic power-law {o.nodes} nodes, nnz {int(nnz_total)} (the N=1 graph), cut into {world} "
+                 f"nnz-balanced row ranges (BASELINE configs[3] at 4)")
+    else:
+        shape = (f"synthetic power-law {o.nodes} nodes/rank ({o.nodes * world} nodes, nnz {int(nnz_total)} total), "
+                 f"row-sharded over {world} ranks (BASELINE configs[4] at 8 with --gnn_type GCN)")
     out = {
         "metric": "DISGAT fwd+SSL-loss edges/sec", "value": nnz_total / (dt / o.steps), "unit": "edges/s",
         "n_gpus": world, "steps": o.steps, "warmup": o.warmup, "ms_per_step": ms, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"synthetic power-law {o.nodes} nodes/rank, nnz {int(nnz_total)} total, F={o.feat}, "
-                               f"H={o.heads}, att={o.att}, gnn_type={o.gnn_type}; {what}; "
-                               + ("BASELINE configs[3] graph on 1 GPU" if world == 1 else f"row-sharded over {world} GPUs"),
-                   "nodes_per_rank": o.nodes, "nnz_total": int(nnz_total), "feat": o.feat, "heads": o.heads,
-                   "att": o.att, "gnn_type": o.gnn_type, "parallelism": f"row-range x{world}",
+        "scaling": "strong" if strong else "weak", "vs_baseline": None,
+        "dtype": "f32 (GEMMs: f16x3 operand split on the fp16 MFMA, fp32 accumulate)" if ops_gemm_mode().startswith("f16x3")
+                 else "f32 (GEMMs: " + ops_gemm_mode() + ")",
+        "data": "synthetic",
+        "config": {"workload": f"{shape}; F={o.feat}, H={o.heads}, att={o.att}, gnn_type={o.gnn_type}; {what}",
+                   "nodes_per_rank": graph.n if strong else o.nodes, "nnz_total": int(nnz_total), "feat": o.feat,
+                   "heads": o.heads, "att": o.att, "gnn_type": o.gnn_type, "parallelism": f"row-range x{world}",
+                   "ranks_seen": world, "backend": None if world == 1 else dist.get_backend(),
                    "gemm_scheme": ops_gemm_mode(), "gemm_check": gemm_chk,
                    "csr_build_ms": None if getattr(graph, "prep_ms", None) is None else round(graph.prep_ms, 1)},
         "roofline": roof, "cpu_baseline": cpu,
     }
+    if rehearsal and world > 1:
+        out["config"]["rehearsal"] = "all ranks share cuda:0 over gloo: functional check of the N-rank path, NOT a scaling number"
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

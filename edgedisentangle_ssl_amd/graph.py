@@ -69,6 +69,7 @@ class CSRGraph:
         self.col = col
         self.row = row                      # int64 [E] (kept for host-side consumers / tests)
         self.n_cols = self.n                # number of nodes a column id can name (> n on a row shard)
+        self.row_start = 0                  # global id of local row 0 (> 0 on a row shard)
         self.nnz = int(col.shape[0])
         self.device = col.device
         self._items = {}

@@ -83,12 +83,25 @@ class _AllGatherRows(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        """Adjoint of the all-gather: every rank holds a gradient for ALL rows; the owner of a row range needs their
+        sum over ranks = one reduce-scatter (each rank receives 1/G of what an all-reduce would move)."""
         counts, group = ctx.counts, ctx.group
         rank = dist.get_rank(group)
+        world = len(counts)
         g = g.contiguous()
-        dist.all_reduce(g, group=group)
-        lo = sum(counts[:rank])
-        return g[lo: lo + counts[rank]], None, None
+        if len(set(counts)) == 1:
+            out = g.new_empty((counts[0],) + tuple(g.shape[1:]))
+            dist.reduce_scatter_tensor(out, g, group=group)
+            return out, None, None
+        mx = max(counts)                          # ragged (nnz-balanced) ranges: pad every range to the longest
+        pad = g.new_zeros((world, mx) + tuple(g.shape[1:]))
+        off = 0
+        for r, c in enumerate(counts):
+            pad[r, :c] = g[off: off + c]
+            off += c
+        out = g.new_empty((mx,) + tuple(g.shape[1:]))
+        dist.reduce_scatter_tensor(out, pad.view((world * mx,) + tuple(g.shape[1:])), group=group)
+        return out[: counts[rank]], None, None
 
 
 def all_gather_rows(x_local, graph):
@@ -100,18 +113,27 @@ def all_gather_rows(x_local, graph):
 
 def all_reduce_grads(modules, graph):
     """Data-parallel gradient reduction: every rank holds the replicated parameters and the gradient
-    contribution of its own rows / pairs; the global gradient is their sum."""
+    contribution of its own rows / pairs; the global gradient is their sum.  The bucket covers EVERY parameter
+    that requires grad in module order (a rank whose shard has no edges / pairs gets None gradients from the
+    backward nodes; zeros stand in for them), so its layout is identical on all ranks; a has-grad flag per parameter
+    rides in the same bucket."""
     if not (isinstance(graph, DistGraph) and graph.world > 1):
         return
-    grads = [p.grad for m in modules for p in m.parameters() if p.grad is not None]
-    if not grads:
+    params = [p for m in modules for p in m.parameters() if p.requires_grad]
+    if not params:
         return
-    flat = torch.cat([g.reshape(-1) for g in grads])          # one bucket: a few MB of parameters
-    dist.all_reduce(flat, group=graph.group)
+    has = torch.tensor([0.0 if p.grad is None else 1.0 for p in params], dtype=params[0].dtype, device=params[0].device)
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params] + [has])
+    dist.all_reduce(flat, group=graph.group)       # one bucket: a few MB of parameters + one has-grad flag each
+    seen = flat[-len(params):].tolist()
     off = 0
-    for g in grads:
-        g.copy_(flat[off: off + g.numel()].view_as(g))
-        off += g.numel()
+    for p, any_rank in zip(params, seen):
+        g = flat[off: off + p.numel()].view_as(p)
+        off += p.numel()
+        if p.grad is not None:
+            p.grad.copy_(g)
+        elif any_rank > 0:                         # unused on every rank (e.g. the encoder's own fusers): stays None,
+            p.grad = g.clone()                     # so the optimiser skips it exactly as in the unsharded run
 
 
 def all_reduce_sum(t, graph):

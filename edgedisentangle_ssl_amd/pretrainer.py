@@ -19,7 +19,7 @@ from . import ops, ops_gemm, parallel, sampling
 from .graph import graph_of
 from .layers import FuseLayer
 from .models import MLP
-from .utils import adj_mse_loss
+from .utils import adj_mse_loss, split
 
 
 def make_adam(params, args):
@@ -29,6 +29,17 @@ def make_adam(params, args):
     params = list(params)
     fused = bool(params) and all(p.is_cuda for p in params)
     return optim.Adam(params, lr=args.lr, weight_decay=args.weight_decay, **({"fused": True} if fused else {}))
+
+
+def _global_count(t, graph):
+    """len(t) summed over the ranks of a sharded graph (python int)."""
+    c = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
+    return int(parallel.all_reduce_sum(c, graph))
+
+
+def _sample(graph, pos, n_pos_global):
+    """Pairs over this process's rows (sampling.py): local row ids, global column ids."""
+    return sampling.sample_pairs(graph.n, pos, n_cols=graph.n_cols, n_pos_global=n_pos_global)
 
 
 def _pair_loss_value(base, h_lo, h_hi, labels, graph):
@@ -135,7 +146,8 @@ class Trainer(object):
         g = graph_of(adj)
         with torch.no_grad():
             feats = self.models[0].get_em(feature, adj, fusers)
-            indices, _ = sampling.sample_pairs(g.n, sampling.flat_edges(g))
+            pos = sampling.flat_edges(g)
+            indices, _ = _sample(g, pos, _global_count(pos, g))
             scores = self.models[0].predict_adjs_sparse(feature, adj, fusers, auxiliary_edges=[indices])
             at_cor, at_dist, feat_cor = [], [], []
             for layer in range(2):
@@ -163,7 +175,11 @@ class SupEdgeTrainer(Trainer):
 
     def sample_train(self, gt):
         g = graph_of(gt)
-        idx, lab = sampling.sample_pairs(g.n, sampling.flat_edges(g))
+        cached = g.__dict__.get("_flat_pos")
+        if cached is None:                    # the positive set of a graph never changes: keep it with the graph
+            pos = sampling.flat_edges(g)
+            cached = g._flat_pos = (pos, _global_count(pos, g))
+        idx, lab = _sample(g, *cached)
         return lab, [idx]
 
     def inference(self, data, sparse_edge_index=None):
@@ -203,20 +219,31 @@ class GeneratedEdgeTrainer(Trainer):
 
     def get_label_all(self, feature, adj, labels, load=True):
         """Flat positive sets of the two edge groups (pretrainer.py:448-456) - O(E), nothing cached
-        on disk (the reference pickles a dense 2 x N x N tensor)."""
+        on disk (the reference pickles a dense 2 x N x N tensor).  `labels` are the GLOBAL node labels; on a row
+        shard rows are offset by the shard's first row and columns are global already.  With --conformT only edges
+        between nodes of the train + val split count as known (pretrainer.py:465-498; the split is drawn here from
+        `random` exactly as the reference draws it)."""
         assert self.dis_type == 1, "currently only use homo&hetero edge disentanglement"
         g = graph_of(adj)
         self.labels = labels
-        same = labels[g.row] == labels[g.col.long()]
+        r_lab, c_lab = labels[g.row + g.row_start], labels[g.col.long()]
+        same, diff = r_lab == c_lab, r_lab != c_lab
+        if getattr(self.args, "conformT", False):
+            idx_train, idx_val, _te, _m = split(labels.cpu(), train_ratio=self.args.node_sup_ratio)
+            known = torch.zeros(labels.shape[0], dtype=torch.bool, device=labels.device)
+            known[torch.cat((idx_train, idx_val)).to(labels.device)] = True
+            both = known[g.row + g.row_start] & known[g.col.long()]
+            same, diff = same & both, diff & both
         flat = sampling.flat_edges(g)
-        self.n = g.n
-        self.dis_adjs = [flat[same], flat[~same]]
+        self.graph = g
+        self.dis_adjs = [flat[same], flat[diff]]
+        self.n_pos_global = [_global_count(p, g) for p in self.dis_adjs]
         return self.dis_adjs
 
     def sample_train(self):
         labs, idxs = [], []
-        for pos in self.dis_adjs:
-            idx, lab = sampling.sample_pairs(self.n, pos)
+        for pos, n_glob in zip(self.dis_adjs, self.n_pos_global):
+            idx, lab = _sample(self.graph, pos, n_glob)
             labs.append(lab)
             idxs.append(idx)
         return labs, idxs

@@ -1,14 +1,11 @@
 """Downstream node-classification trainer on top of the DISGAT path (mirror of the reference's
 trainer.py:16-32, 150-223, 297-320).  A caller of the hot path, kept for drop-in completeness."""
-import random
-
-import numpy as np
 import torch
 import torch.nn.functional as F
 
 from .models import MLP
 from .pretrainer import Trainer, make_adam
-from .utils import accuracy
+from .utils import accuracy, split  # noqa: F401  (split re-exported: callers import it from here too)
 
 
 def fuse_feature(feature_list, fuse="last"):
@@ -21,26 +18,6 @@ def fuse_feature(feature_list, fuse="last"):
 
 def cal_feat_dim(args):
     return args.nhid * (args.enc_layer if args.fuse == "concat" else 1)
-
-
-def split(labels, train_ratio=0.25):
-    """Per-class random train/val/test split (utils.py:118-161); same draw order from `random`."""
-    val_ratio, test_ratio = (1 - train_ratio) / 4, (1 - train_ratio) / 4 * 3
-    num_classes = len(set(labels.tolist()))
-    train_idx, val_idx, test_idx = [], [], []
-    c_num_mat = np.zeros((num_classes, 3)).astype(int)
-    for i in range(num_classes):
-        c_idx = (labels == i).nonzero()[:, -1].tolist()
-        random.shuffle(c_idx)
-        if len(c_idx) < 11:
-            raise ValueError("too small class type: {}, num{}".format(i, len(c_idx)))
-        c_num_mat[i] = [int(len(c_idx) * train_ratio), int(len(c_idx) * val_ratio), int(len(c_idx) * test_ratio)]
-        a, b, c = c_num_mat[i]
-        train_idx += c_idx[:a]
-        val_idx += c_idx[a:a + b]
-        test_idx += c_idx[a + b:a + b + c]
-    random.shuffle(train_idx)
-    return torch.LongTensor(train_idx), torch.LongTensor(val_idx), torch.LongTensor(test_idx), c_num_mat
 
 
 def roc_f(output, labels):

@@ -5,7 +5,9 @@ command lines written for the reference's main.py parse unchanged.  Only --model
 implemented by this package; the other encoders are out of scope.
 """
 import argparse
+import random
 
+import numpy as np
 import torch
 
 _FLAGS = [
@@ -96,3 +98,23 @@ def group_correlation(embedding):
     gram = centred @ centred.t()
     norm = torch.sqrt(torch.diagonal(gram))
     return gram / torch.outer(norm, norm)
+
+
+def split(labels, train_ratio=0.25):
+    """Per-class random train/val/test split (utils.py:118-161); same draw order from `random`."""
+    val_ratio, test_ratio = (1 - train_ratio) / 4, (1 - train_ratio) / 4 * 3
+    num_classes = len(set(labels.tolist()))
+    train_idx, val_idx, test_idx = [], [], []
+    c_num_mat = np.zeros((num_classes, 3)).astype(int)
+    for i in range(num_classes):
+        c_idx = (labels == i).nonzero()[:, -1].tolist()
+        random.shuffle(c_idx)
+        if len(c_idx) < 11:
+            raise ValueError("too small class type: {}, num{}".format(i, len(c_idx)))
+        c_num_mat[i] = [int(len(c_idx) * train_ratio), int(len(c_idx) * val_ratio), int(len(c_idx) * test_ratio)]
+        a, b, c = c_num_mat[i]
+        train_idx += c_idx[:a]
+        val_idx += c_idx[a:a + b]
+        test_idx += c_idx[a + b:a + b + c]
+    random.shuffle(train_idx)
+    return torch.LongTensor(train_idx), torch.LongTensor(val_idx), torch.LongTensor(test_idx), c_num_mat

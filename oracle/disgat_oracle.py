@@ -46,6 +46,13 @@ def sp_matmul(rows, cols, values, mat):
     return out.index_add(0, rows, values * mat[cols])
 
 
+# The att-3 nonlinearity, F.leaky_relu with the default slope 0.01 (layers.py:377).  A module attribute so that a
+# gradient test can pin the side taken at |z| within rounding of the kink (an fp32 and an fp64 evaluation may land on
+# different sides of z = 0, which flips that term's derivative between 0.01 and 1 - a property of the function,
+# tests/test_gpu_bench_shape.py); nothing else ever rebinds it.
+LRELU3 = F.leaky_relu
+
+
 # ----------------------------------------------------------------------------- layers.py:349-389
 def pair_score(att, x, W, a, r, c):
     """Raw (pre-sigmoid) attention score of node pairs (r_k, c_k); [K,1]."""
@@ -57,7 +64,7 @@ def pair_score(att, x, W, a, r, c):
         return (h[r] * h[c]).sum(-1, keepdim=True)
     if att == 3:                                   # layers.py:374-379 (leaky_relu slope 0.01)
         z = torch.cat([x[r], x[c]], dim=1) @ W
-        return F.leaky_relu(z) @ a
+        return LRELU3(z) @ a
     raise ValueError(att)
 
 

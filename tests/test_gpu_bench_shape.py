@@ -1,0 +1,92 @@
+"""The EXACT kernel instantiation bench.py times (H = 8, F_in = F_out = 256, att 3 -> edge_fwd_kernel<3,3,8,1>,
+aux_att3_kernel<3,8>), on the bench workload's own generator at an oracle-reachable size
+(synth.powerlaw_graph(2048, 40960): the cpu_baseline sample): get_em, the three SSL losses and every parameter
+gradient against the float64 oracle, for the three inner layer types (reference: layers.py:374-389,
+pretrainer.py:612-627, 727-739, 819-832)."""
+import pytest
+import torch
+
+import kink
+from test_gpu_parity import close, dev, make_args  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+N, E, F, H = 2048, 40960, 256, 8
+
+
+def _sd(mod):
+    return {k: v.detach().cpu().double().requires_grad_(True) for k, v in mod.state_dict().items()}
+
+
+@pytest.mark.parametrize("gnn", ["AT", "SAGE", "GCN"])
+def test_bench_workload_shape_vs_oracle(dev, gnn):
+    import edgedisentangle_ssl_amd as pkg
+    from edgedisentangle_ssl_amd import pretrainer, synth
+    from oracle import disgat_oracle as orc
+
+    a = make_args(gnn, 3, H, F, F, lr=0.01, weight_decay=5e-4, dis_type=1)
+    graph = synth.powerlaw_graph(N, E, dev)
+    labels = synth.node_labels(N, dev)
+    (si, sl), (hi, hl), (ti, tl) = synth.ssl_lists(graph, labels)
+    if gnn != "AT":            # the pair scorer does not depend on the inner layer type: every 4th pair keeps the float64
+        si, sl, hi, hl, ti, tl = (t[..., ::4].contiguous() for t in (si, sl, hi, hl, ti, tl))     # oracle to ~1 min
+    x = synth.features(N, F, dev)
+    torch.manual_seed(0)                                   # the reference initialisers, as bench.py draws them
+    enc = pkg.DISGAT(a, nfeat=F, nhid=F, nclass=F, nheads=H, dropout=0.0).to(dev).eval()
+    sup = pretrainer.SupEdgeTrainer(a, enc, 1.0)
+    dis = pretrainer.GeneratedEdgeTrainer(a, enc, 1.0)
+    dif = pretrainer.DifHeadTrainer(a, enc, 1.0)
+    for tr in (sup, dis, dif):
+        for m in tr.models:
+            m.eval()
+    ei = graph.indices().cpu()
+    xc = x.cpu().double()
+    edges = (ei[0], ei[1])
+
+    # ---- forward: get_em (no kink dependence)
+    with torch.no_grad():
+        em = enc.get_em(x, graph, [sup.fuse1, sup.fuse2])
+        sd0 = {k: v.detach().cpu().double() for k, v in enc.state_dict().items()}
+        f0 = [(lambda hs, r, p={k: v.detach().cpu().double() for k, v in f.state_dict().items()}: orc.fuse_layer(p, hs, r))
+              for f in (sup.fuse1, sup.fuse2)]
+        ref = orc.disgat_pass(sd0, xc, ei, f0, H, 3, gnn)
+    for l in range(2):
+        close(em[l], ref["feat"][l], what=f"{gnn} get_em[{l}]")
+    del ref
+
+    def run(tr, gpu_loss, lists, ref_loss):
+        """One loss on the GPU (with autograd) and in the float64 oracle under the kernels' kink sides."""
+        mods = tr.models
+        for m in mods:
+            for p in m.parameters():
+                p.grad = None
+        rec = []
+        with kink.record_operands(rec):
+            loss = gpu_loss()
+        loss.backward()
+        sds = [_sd(m) for m in mods]
+        fus = [(lambda hs, r, p=sds[k]: orc.fuse_layer(p, hs, r)) for k in (1, 2)]
+        pins = kink.Pins(rec, H, F, [edges] + [(i_[0].cpu(), i_[1].cpu()) for i_ in lists])
+        with kink.pinned_oracle(pins):
+            r = orc.disgat_pass(sds[0], xc, ei, fus, H, 3, gnn, [i_.cpu() for i_ in lists] or None)
+        want = ref_loss(r, sds)
+        want.backward()
+        assert pins.calls == 2 * H * (1 + len(lists)) and pins.disagree_far == 0, (pins.calls, pins.disagree_far)
+        close(loss, want.detach(), tol=1e-5, what=f"{gnn} {type(tr).__name__} loss")
+        for m, sd in zip(mods, sds):
+            for k, p in m.named_parameters():
+                if m is enc and k.startswith(("fuser1", "fuser2")):
+                    continue                                # the encoder's own fusers are unused (is_specific)
+                g_ref = sd[k].grad if sd[k].grad is not None else torch.zeros_like(sd[k])
+                g_got = p.grad if p.grad is not None else torch.zeros_like(p)
+                close(g_got, g_ref, tol=2e-4, what=f"{gnn} {type(tr).__name__} grad {k}")
+        return pins.pinned
+
+    data = (x, graph)
+    n_pinned = run(sup, lambda: sup.loss(data, sl, [si]), [si],
+                   lambda r, sds: orc.sup_edge_loss(r["aux"], sl.cpu().double()))
+    n_pinned += run(dis, lambda: dis.loss(data, [hl, tl], [hi, ti]), [hi, ti],
+                    lambda r, sds: orc.dis_edge_loss(r["aux"], hl.cpu().double(), tl.cpu().double()))
+    n_pinned += run(dif, lambda: dif.loss(data), [],
+                    lambda r, sds: orc.dif_head_loss(r["edge_em"], sds[3], sds[4]))
+    print(f"[bench-shape {gnn}] leaky-ReLU arguments within 1e-5 of the kink (sides pinned to the kernels'): {n_pinned}")

@@ -1,0 +1,102 @@
+"""Distribution of the O(E) pair sampler (sampling.sample_pairs) against the reference's dense-mask sampler
+(pretrainer.py:683-707, 524-576): mask = Bernoulli(3*rho) over all N^2 entries united with a third of the
+positives.  The reference's own draw on the tiny graph is recorded in tests/golden/tiny_ref_sampler.npz; one draw
+cannot be matched entry for entry (different RNG streams), so the test compares distributions:
+  * M = K + n_pos//3 - overlap with K ~ Binomial(N^2, 3 rho): mean and spread of our M over many draws against the
+    closed form, and the reference's recorded M inside that spread;
+  * every positive appears with probability 1/3 + 2/3 * 3 rho, every negative with probability 3 rho;
+  * the random part is uniform over rows (per-row counts are Binomial(N, 3 rho));
+  * structure: row-major sorted, unique, labels == membership.
+Runs on the CPU here and on the GPU (the sampler is device code only through torch ops)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import inputs_common as ic
+
+
+def _stats(dev, golden_dir, draws=600):
+    from edgedisentangle_ssl_amd import sampling
+    from edgedisentangle_ssl_amd.graph import CSRGraph
+    idx, _vals, n = ic.tiny_graph()
+    g = CSRGraph.from_index(idx.to(dev), n)
+    pos = sampling.flat_edges(g)
+    npos = int(pos.numel())
+    gen = torch.Generator(device=dev).manual_seed(11)
+    hgen = torch.Generator().manual_seed(12)
+    p3 = 3.0 * npos / (n * n)
+    ms, hit = [], torch.zeros(n * n, device=dev)
+    for _ in range(draws):
+        pidx, lab = sampling.sample_pairs(n, pos, gen, host_generator=hgen)
+        flat = pidx[0] * n + pidx[1]
+        assert torch.all(flat[1:] > flat[:-1])                       # mask.nonzero() order, no duplicates
+        assert torch.equal(lab, torch.isin(flat, pos).float())
+        assert int(pidx.min()) >= 0 and int(pidx.max()) < n
+        hit[flat] += 1
+        ms.append(int(flat.numel()))
+    ms = np.asarray(ms, dtype=np.float64)
+    third = npos // 3
+    # E[M] = N^2 p3 + third * (1 - p3);  Var[M] = (N^2 - third) p3 (1 - p3)   (entries outside the third are Bernoulli)
+    mean = n * n * p3 + third * (1 - p3)
+    var = (n * n - third) * p3 * (1 - p3)
+    assert abs(ms.mean() - mean) < 4 * np.sqrt(var / draws), (ms.mean(), mean)
+    assert 0.8 * var < ms.var() < 1.25 * var, (ms.var(), var)
+    ref = np.load(os.path.join(golden_dir, "tiny_ref_sampler.npz"))
+    m_ref = ref["sup_idx"].shape[1]
+    assert abs(m_ref - mean) < 4 * np.sqrt(var), (m_ref, mean)       # the reference's own draw is a typical one
+    assert abs(ref["sup_lab"].mean() - (third + (npos - third) * p3) / mean) < 0.05
+    freq = (hit / draws).cpu().numpy()
+    is_pos = np.zeros(n * n, dtype=bool)
+    is_pos[pos.cpu().numpy()] = True
+    p_pos = third / npos + (1 - third / npos) * p3
+    assert abs(freq[is_pos].mean() - p_pos) < 4 * np.sqrt(p_pos * (1 - p_pos) / (draws * is_pos.sum()))
+    assert abs(freq[~is_pos].mean() - p3) < 4 * np.sqrt(p3 * (1 - p3) / (draws * (~is_pos).sum()))
+    per_row = freq.reshape(n, n)[:, :].copy()
+    per_row[is_pos.reshape(n, n)] = np.nan                           # negatives only: uniform over rows and columns
+    rows = np.nanmean(per_row, 1)
+    assert np.all(np.abs(rows - p3) < 6 * np.sqrt(p3 * (1 - p3) / (draws * (n - 8)))), rows
+    cols = np.nanmean(per_row, 0)
+    assert np.all(np.abs(cols - p3) < 6 * np.sqrt(p3 * (1 - p3) / (draws * (n - 24)))), cols
+
+
+def test_sampler_distribution_cpu(golden_dir):
+    _stats(torch.device("cpu"), golden_dir)
+
+
+@pytest.mark.gpu
+def test_sampler_distribution_gpu(golden_dir):
+    _stats(torch.device("cuda:0"), golden_dir)
+
+
+def test_binomial_count_and_subset():
+    from edgedisentangle_ssl_amd import sampling
+    g = torch.Generator().manual_seed(0)
+    ks = np.array([sampling.binomial_count(10 ** 12, 6e-5, g) for _ in range(200)], dtype=np.float64)
+    assert abs(ks.mean() - 6e7) < 4 * np.sqrt(6e7 / 200) and 0.7 * 6e7 < ks.var() < 1.4 * 6e7
+    assert sampling.binomial_count(0, 0.5) == 0 and sampling.binomial_count(10, 0.0) == 0
+    s = sampling.uniform_subset(50, 45, torch.device("cpu"), g)       # dense case: many collisions, still 45 distinct
+    assert s.numel() == 45 and torch.all(s[1:] > s[:-1]) and int(s.max()) < 50
+    assert sampling.uniform_subset(10, 99, torch.device("cpu"), g).numel() == 10
+
+
+def test_sampler_on_a_row_shard():
+    """Rows local, columns global (flat ids must use n_cols, not n_local)."""
+    from edgedisentangle_ssl_amd import parallel, sampling
+    from edgedisentangle_ssl_amd.graph import CSRGraph
+    idx, _vals, n = ic.tiny_graph()
+    g = CSRGraph.from_index(idx, n)
+    full = set((g.row * n + g.col.long()).tolist())
+    gen = torch.Generator().manual_seed(5)
+    seen_pos = 0
+    for rank in range(3):
+        dg = parallel.DistGraph.shard(g, rank, 3)
+        pos = sampling.flat_edges(dg)
+        assert torch.all(pos[1:] > pos[:-1])
+        pidx, lab = sampling.sample_pairs(dg.n, pos, gen, n_cols=dg.n_cols, n_pos_global=g.nnz)
+        assert int(pidx[0].max()) < dg.n and int(pidx[1].max()) < n and int(pidx[1].max()) >= dg.n   # columns span all nodes
+        glob = ((pidx[0] + dg.row_start) * n + pidx[1]).tolist()
+        assert [float(f in full) for f in glob] == lab.tolist()
+        seen_pos += int(lab.sum())
+    assert seen_pos >= g.nnz // 3 - 3
