@@ -14,7 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libdisgat_hip.so")
-SOURCES = ["api_common.hip", "edge_fwd.hip", "aux_score.hip", "edge_bwd.hip", "gemm_split.hip"]
+SOURCES = ["api_common.hip", "edge_fwd.hip", "aux_score.hip", "edge_bwd.hip", "gemm_split.hip", "optim.hip"]
 ARCH = "gfx950"
 
 _lib = None
@@ -95,11 +95,12 @@ _SIGS = {
     "disgat_bwd_alpha": (_c.c_int, [_P, _c.c_int, _P, _c.c_int64, _c.c_int, _c.c_int, _P, _c.c_int, _P, _P, _P, _P, _P,
                                     _P, _P, _c.c_int, _c.c_float, _c.c_uint64, _P]),
     "disgat_seg_grad_att3": (_c.c_int, [_P, _c.c_int, _P, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
-                                        _P, _c.c_int, _P, _c.c_int, _P, _P, _c.c_int, _P, _c.c_int, _P]),
+                                        _P, _c.c_int, _P, _c.c_int, _P, _P, _c.c_int, _P, _c.c_int, _P, _P]),
     "disgat_seg_grad_sign": (_c.c_int, [_P, _c.c_int, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P,
-                                        _P, _c.c_int, _P, _P, _c.c_int, _P, _c.c_int, _c.c_int, _P]),
+                                        _P, _c.c_int, _P, _P, _c.c_int, _P, _c.c_int, _c.c_int, _P, _P]),
     "disgat_seg_grad_hx": (_c.c_int, [_c.c_int, _P, _c.c_int, _P, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int,
-                                      _c.c_int, _P, _c.c_int, _P, _c.c_int, _c.c_int, _P]),
+                                      _c.c_int, _P, _c.c_int, _P, _c.c_int, _c.c_int, _P, _P]),
+    "disgat_seg_combine": (_c.c_int, [_P, _P, _c.c_int, _c.c_int, _P, _P, _c.c_int, _c.c_int, _P]),
     "disgat_gemm_split": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _P, _P, _P, _c.c_int64, _c.c_int64, _P, _c.c_int64,
                                      _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_float,
                                      _c.c_int, _P]),
@@ -111,6 +112,7 @@ _SIGS = {
     "disgat_split_f16": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _P, _P, _P]),
     "disgat_amax": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _P, _P]),
     "disgat_act_bwd": (_c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int, _c.c_float, _P, _P]),
+    "disgat_adam_multi": (_c.c_int, [_c.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _c.c_float, _c.c_float, _c.c_float, _P]),
 }
 
 

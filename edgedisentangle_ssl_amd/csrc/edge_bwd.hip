@@ -23,6 +23,13 @@
 
 namespace disgat {
 
+// Where a work item's result goes: a whole key's row of gkey, or - for a key split across several work items (hub
+// rows / columns) - that slice's own partial record part[slot] (row layout of gkey), which seg_combine_kernel adds in
+// slice order afterwards (deterministic).  part == null keeps the older behaviour: atomic adds into a zeroed row.
+__device__ __forceinline__ float* seg_out_row(float* gkey, float* part, int ld, int key, int slot) {
+  return (slot >= 0 && part != nullptr) ? part + (size_t)slot * ld : gkey + (size_t)key * ld;
+}
+
 __device__ __forceinline__ void out4(float* p, f32x4 v, bool atomic, bool accumulate) {
   if (atomic) {
     atomicAdd(p + 0, v.x);
@@ -174,6 +181,7 @@ struct SegArgs {
   int ld_gkey;
   float* ga_part;        // [n_waves][H*FQ] or null
   int accumulate;
+  float* part;           // [n_slots][ld_gkey] partial records of split keys, or null (atomics)
 };
 
 template <int HL, int QN>
@@ -243,9 +251,10 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void seg_grad_att3_kernel(const Se
       }
       if (i < cnt) compute(qA, __builtin_amdgcn_readlane(pv, i));
     }
-    float* op = A.gkey + (size_t)key * A.ld_gkey + qoff;
+    float* op = seg_out_row(A.gkey, A.part, A.ld_gkey, key, slot) + qoff;
+    const bool to_part = slot >= 0 && A.part != nullptr;
 #pragma unroll
-    for (int j = 0; j < QN; ++j) out4(op + j * G * 4, gk[j], slot >= 0, A.accumulate != 0);
+    for (int j = 0; j < QN; ++j) out4(op + j * G * 4, gk[j], slot >= 0 && !to_part, A.accumulate != 0 && !to_part);
   }
   if (A.ga_part != nullptr) {
     float* gp = A.ga_part + (size_t)wave * (FQ << HL) + qoff;
@@ -278,6 +287,7 @@ struct SignArgs {
   int ld_gkey;
   float* ga_part;        // [n_waves][H*FQ] or null
   int accumulate;        // 1: add into gkey (heads outside [h_lo, h_hi) are left untouched) instead of storing
+  float* part;           // [n_slots][ld_gkey] partial records of split keys, or null (atomics)
 };
 
 template <int HL, int QN>
@@ -338,14 +348,16 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void seg_grad_sign_kernel(const Si
         if (i + 4 < cnt) accum(wB, gB);
       }
     }
-    float* op = A.gkey + (size_t)key * A.ld_gkey + qoff;
+    float* op = seg_out_row(A.gkey, A.part, A.ld_gkey, key, slot) + qoff;
+    const bool to_part = slot >= 0 && A.part != nullptr;      // a partial record is always stored whole (zeros for idle heads)
     const float base = 0.01f * gall;
     const float* pp = A.keyop + (size_t)key * A.ld_key + qoff;
 #pragma unroll
     for (int j = 0; j < QN; ++j) {           // a (8 KB, cache-resident) and the key's operand row are read here, once per item
       const f32x4 u = 0.99f * up[j] + base;
       if (want_ga) ga[j] += ld4(pp + j * G * 4) * u;
-      if (!A.accumulate || active) out4(op + j * G * 4, ld4(A.a + qoff + j * G * 4) * u, slot >= 0, A.accumulate != 0);
+      if (to_part || !A.accumulate || active)
+        out4(op + j * G * 4, ld4(A.a + qoff + j * G * 4) * u, slot >= 0 && !to_part, A.accumulate != 0 && !to_part);
     }
   }
   if (want_ga) {
@@ -400,12 +412,13 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void seg_grad_hx_row_kernel(const 
     }
     if (i < cnt) compute(xA, cA);
   }
-  float* op = A.gkey + (size_t)key * A.ld_gkey + xoff;
+  float* op = seg_out_row(A.gkey, A.part, A.ld_gkey, key, slot) + xoff;
+  const bool to_part = slot >= 0 && A.part != nullptr;
 #pragma unroll
   for (int hh = 0; hh < H; ++hh)
 #pragma unroll
     for (int i = 0; i < XN; ++i)
-      if (i * 256 + xoff < A.F) out4(op + hh * A.F + i * 256, acc[hh * XN + i], slot >= 0, A.accumulate != 0);
+      if (i * 256 + xoff < A.F) out4(op + hh * A.F + i * 256, acc[hh * XN + i], slot >= 0 && !to_part, A.accumulate != 0 && !to_part);
 }
 
 // gkey[key][:] (+)= sum_m sum_h coef[h][pos(m)] * Mx[other_m][h][:]
@@ -457,10 +470,25 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void seg_grad_hx_col_kernel(const 
     }
     if (i < cnt) compute(mA, cA);
   }
-  float* op = A.gkey + (size_t)key * A.ld_gkey + xoff;
+  float* op = seg_out_row(A.gkey, A.part, A.ld_gkey, key, slot) + xoff;
+  const bool to_part = slot >= 0 && A.part != nullptr;
 #pragma unroll
   for (int i = 0; i < XN; ++i)
-    if (i * 256 + xoff < A.F) out4(op + i * 256, acc[i], slot >= 0, A.accumulate != 0);
+    if (i * 256 + xoff < A.F) out4(op + i * 256, acc[i], slot >= 0 && !to_part, A.accumulate != 0 && !to_part);
+}
+
+// gkey[key][0:width] (+)= sum of the key's partial records, in slice order: one block per split key.
+__global__ __launch_bounds__(256) void seg_combine_kernel(const int32_t* __restrict__ split_keys, const int32_t* __restrict__ split_ptr,
+                                                          int width, const float* __restrict__ part, int ld, float* __restrict__ gkey,
+                                                          int accumulate) {
+  const int key = split_keys[blockIdx.x];
+  const int s0 = split_ptr[blockIdx.x], s1 = split_ptr[blockIdx.x + 1];
+  float* out = gkey + (size_t)key * ld;
+  for (int c = threadIdx.x * 4; c < width; c += 256 * 4) {
+    f32x4 acc = accumulate ? ld4(out + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int sl = s0; sl < s1; ++sl) acc += ld4(part + (size_t)sl * ld + c);
+    st4(out + c, acc);
+  }
 }
 
 }  // namespace disgat
@@ -518,7 +546,8 @@ static int seg_common_checks(const char* who, const int32_t* items, int n_items,
 extern "C" int disgat_seg_grad_att3(const int32_t* items, int n_items, const int32_t* other, const int32_t* perm,
                                     const float* g, int64_t g_stride, int h_lo, int h_hi, int H, int F_out,
                                     const float* keyop, int ld_key, const float* otherop, int ld_other, const float* a,
-                                    float* gkey, int ld_gkey, float* ga_part, int n_waves, disgat_stream_t stream) {
+                                    float* gkey, int ld_gkey, float* ga_part, int n_waves, float* part,
+                                    disgat_stream_t stream) {
   using namespace disgat;
   if (n_items == 0) return 0;
   if (int rc = seg_common_checks("seg_grad_att3", items, n_items, other, g, H, h_lo, h_hi, otherop, gkey)) return rc;
@@ -528,7 +557,7 @@ extern "C" int disgat_seg_grad_att3(const int32_t* items, int n_items, const int
   DISGAT_REQUIRE(n_waves > 0 && n_waves % DISGAT_WAVES_PER_BLOCK == 0, "seg_grad_att3: n_waves must be a positive multiple of %d", DISGAT_WAVES_PER_BLOCK);
   const int qn = F_out / g4;
   SegArgs A{reinterpret_cast<const int4*>(items), n_items, other, perm, g, g_stride, h_lo, h_hi, F_out, keyop, ld_key,
-            otherop, ld_other, a, gkey, ld_gkey, ga_part, 0};
+            otherop, ld_other, a, gkey, ld_gkey, ga_part, 0, part};
   const dim3 grid(n_waves / DISGAT_WAVES_PER_BLOCK), block(DISGAT_BLOCK);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 #define DISGAT_SG(HL_, QN_) hipLaunchKernelGGL((seg_grad_att3_kernel<HL_, QN_>), grid, block, 0, s, A)
@@ -554,7 +583,7 @@ extern "C" int disgat_seg_grad_att3(const int32_t* items, int n_items, const int
 extern "C" int disgat_seg_grad_sign(const int32_t* items, int n_items, const int32_t* perm, const float* g,
                                     int64_t g_stride, int h_lo, int h_hi, int H, int F_out, const uint32_t* sign_bits,
                                     const float* keyop, int ld_key, const float* a, float* gkey, int ld_gkey,
-                                    float* ga_part, int n_waves, int accumulate, disgat_stream_t stream) {
+                                    float* ga_part, int n_waves, int accumulate, float* part, disgat_stream_t stream) {
   using namespace disgat;
   if (n_items == 0) return 0;
   const int hl = ilog2_exact(H);
@@ -569,7 +598,7 @@ extern "C" int disgat_seg_grad_sign(const int32_t* items, int n_items, const int
   DISGAT_REQUIRE(n_waves > 0 && n_waves % DISGAT_WAVES_PER_BLOCK == 0, "seg_grad_sign: n_waves must be a positive multiple of %d", DISGAT_WAVES_PER_BLOCK);
   const int qn = F_out / g4;
   SignArgs A{reinterpret_cast<const int4*>(items), n_items, perm, g, g_stride, h_lo, h_hi, sign_bits, keyop, ld_key, a,
-             gkey, ld_gkey, ga_part, accumulate};
+             gkey, ld_gkey, ga_part, accumulate, part};
   const dim3 grid(n_waves / DISGAT_WAVES_PER_BLOCK), block(DISGAT_BLOCK);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 #define DISGAT_SS(HL_, QN_) hipLaunchKernelGGL((seg_grad_sign_kernel<HL_, QN_>), grid, block, 0, s, A)
@@ -624,15 +653,27 @@ static int launch_hx(const disgat::SegArgs& A, int hl, int xn, hipStream_t s) {
 extern "C" int disgat_seg_grad_hx(int col_mode, const int32_t* items, int n_items, const int32_t* other,
                                   const int32_t* perm, const float* coef, int64_t coef_stride, int h_lo, int h_hi, int H,
                                   int F, const float* otherop, int ld_other, float* gkey, int ld_gkey, int accumulate,
-                                  disgat_stream_t stream) {
+                                  float* part, disgat_stream_t stream) {
   using namespace disgat;
   if (n_items == 0) return 0;
   if (int rc = seg_common_checks("seg_grad_hx", items, n_items, other, coef, H, h_lo, h_hi, otherop, gkey)) return rc;
   DISGAT_REQUIRE(F > 0 && F % 4 == 0 && ld_other % 4 == 0 && ld_gkey % 4 == 0, "seg_grad_hx: F/strides must be multiples of 4");
   SegArgs A{reinterpret_cast<const int4*>(items), n_items, other, perm, coef, coef_stride, h_lo, h_hi, F, nullptr, 0,
-            otherop, ld_other, nullptr, gkey, ld_gkey, nullptr, accumulate};
+            otherop, ld_other, nullptr, gkey, ld_gkey, nullptr, accumulate, part};
   const int hl = ilog2_exact(H);
   const int xn = (F + 255) / 256;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   return col_mode ? launch_hx<true>(A, hl, xn, s) : launch_hx<false>(A, hl, xn, s);
+}
+
+extern "C" int disgat_seg_combine(const int32_t* split_keys, const int32_t* split_ptr, int n_split, int width,
+                                  const float* part, float* gkey, int ld_gkey, int accumulate, disgat_stream_t stream) {
+  using namespace disgat;
+  if (n_split == 0) return 0;
+  DISGAT_REQUIRE(split_keys && split_ptr && part && gkey, "seg_combine: null pointer");
+  DISGAT_REQUIRE(width > 0 && width % 4 == 0 && width <= ld_gkey && ld_gkey % 4 == 0 && aligned16(part) && aligned16(gkey),
+                 "seg_combine: width / stride must be multiples of 4 floats (width <= stride), bases 16-byte aligned");
+  hipLaunchKernelGGL(seg_combine_kernel, dim3(n_split), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), split_keys,
+                     split_ptr, width, part, ld_gkey, gkey, accumulate);
+  return check_launch("seg_combine_kernel");
 }

@@ -79,6 +79,10 @@ class CSRGraph:
     @staticmethod
     def from_index(indices, n):
         """indices: int64 [2, nnz_raw] (possibly unsorted, with duplicates)."""
+        if indices.numel():
+            lo, hi = torch.aminmax(indices)          # once per adjacency: a bad id would be a GPU fault later
+            if int(lo) < 0 or int(hi) >= n:
+                raise ValueError(f"adjacency index out of range: ids in [{int(lo)},{int(hi)}] for {n} nodes")
         flat = torch.unique(indices[0].to(torch.int64) * n + indices[1].to(torch.int64))
         row = torch.div(flat, n, rounding_mode="floor")
         col = (flat - row * n).to(torch.int32)

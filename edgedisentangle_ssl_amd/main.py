@@ -14,7 +14,7 @@ import torch
 
 from . import data_load, models, pretrainer, trainer
 from .features import surrogate_features
-from .utils import get_parser
+from .utils import get_parser, resolve_logs
 
 SSL = {"DisEdge": pretrainer.GeneratedEdgeTrainer, "SupEdge": pretrainer.SupEdgeTrainer, "DifHead": pretrainer.DifHeadTrainer}
 
@@ -50,6 +50,12 @@ def run(argv=None, log=print):
     args = parser.parse_args(argv)
     if args.model != "DISGAT":
         raise SystemExit("only --model=DISGAT is implemented by this package (SURVEY 2: other encoders out of scope)")
+    for flag, why in (("batch", "sub-graph mini-batching (dataset.py) is outside the DISGAT hot path (SURVEY 2 row 22)"),
+                      ("hnn", "the heterogeneous-network encoders are outside the DISGAT hot path (SURVEY 2 row 17)"),
+                      ("case", "the --case heat-map study is reporting only (SURVEY 2 row 23); "
+                               "Trainer.analyze_disentangle returns the same grids")):
+        if getattr(args, flag):
+            raise SystemExit("--{}: {}".format(flag, why))
     if not torch.cuda.is_available() or args.no_cuda:
         raise SystemExit("the DISGAT HIP path needs an MI355X; there is no CPU fallback")
     args.cuda = True
@@ -115,6 +121,7 @@ def run(argv=None, log=print):
         for i, tr in enumerate(ssl_trainers):
             a = adjs[args.pre_edge[i] - 1]
             log_ep.update(tr.train_step([features, a], ssl_labels[i]))
+        log_ep = resolve_logs(log_ep)                    # the step logs are device scalars: one transfer per epoch
         history.append(log_ep)
         if not args.quiet:
             log(" ".join("{}={:.5g}".format(k, v) if isinstance(v, float) else "{}={}".format(k, v) for k, v in log_ep.items()))

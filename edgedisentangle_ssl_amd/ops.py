@@ -117,12 +117,41 @@ def edge_forward(graph: CSRGraph, att, H, F_in, F_out, x, rowop, colop, a, sage_
     return z, edge_e, den
 
 
+# The kernels index the operand tables with the ids they are given: an out-of-range pair id is a GPU fault, not an
+# exception.  With CHECK_INDICES on, every pair list is range-checked once on the host side (one aminmax per tensor
+# OBJECT - the verdict is remembered on the tensor, so the second layer and later steps on the same list do not
+# synchronise again; lists produced by sampling.sample_pairs are in range by construction and arrive pre-marked).
+CHECK_INDICES = True
+
+
+def mark_checked(pairs):
+    pairs._disgat_in_range = True
+    return pairs
+
+
+def check_pairs(pairs, n_rows, n_cols):
+    if not CHECK_INDICES or getattr(pairs, "_disgat_in_range", False) or pairs.shape[1] == 0:
+        return
+    r_lo, r_hi = torch.aminmax(pairs[0])
+    c_lo, c_hi = torch.aminmax(pairs[1])
+    r_lo, r_hi, c_lo, c_hi = torch.stack([r_lo, r_hi, c_lo, c_hi]).tolist()
+    if r_lo < 0 or c_lo < 0 or r_hi >= n_rows or c_hi >= n_cols:
+        raise RuntimeError(f"auxiliary pair list out of range: rows in [{r_lo},{r_hi}] (must be < {n_rows}), "
+                           f"columns in [{c_lo},{c_hi}] (must be < {n_cols})")
+    try:
+        pairs._disgat_in_range = True
+    except AttributeError:
+        pass
+
+
 def aux_forward(att, H, F_in, F_out, pairs, n, x, rowop, colop, a, h_lo=0, h_hi=None, sign=None):
     """Launch disgat_aux_score.  pairs: int64 [2,M] device tensor.  Returns [H,M]
     (rows outside [h_lo,h_hi) are left uninitialised and must not be read)."""
-    if pairs.dtype != torch.int64 or not pairs.is_cuda:
+    if pairs.dtype != torch.int64 or not pairs.is_cuda or pairs.dim() != 2 or pairs.shape[0] != 2:
         raise RuntimeError("auxiliary pair list must be an int64 device tensor of shape (2,M)")
     h_hi = H if h_hi is None else h_hi
+    # row ids index rowop (the rows this process owns); column ids index colop, or x for att 2 (every node)
+    check_pairs(pairs, rowop.shape[0], (colop if colop is not None else x).shape[0])
     pairs = pairs.contiguous()
     m = int(pairs.shape[1])
     out = torch.empty((H, m), dtype=torch.float32, device=pairs.device)

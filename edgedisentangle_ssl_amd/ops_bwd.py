@@ -11,15 +11,34 @@ def _buf(shape, dev, zero):
     return (torch.zeros if zero else torch.empty)(shape, dtype=torch.float32, device=dev)
 
 
+# Keys split across several work items (hub rows / columns): True = every slice writes its own partial record and
+# disgat_seg_combine adds them in slice order (run-to-run deterministic gradients); False = float atomics into zeroed
+# rows (the round-1 behaviour, kept for comparison).
+DETERMINISTIC = True
+
+
 def _keybuf(shape, dev, wi, force_zero=False):
-    """Output rows of a segment pass: whole keys are stored, keys split across work items are accumulated with
-    atomics, so only THOSE rows need zeroing (a handful of hub rows, not the whole multi-GB buffer)."""
+    """Output rows of a segment pass: whole keys are stored; split keys are written by the combine pass (or, with
+    DETERMINISTIC off, accumulated with atomics into rows zeroed here - a handful of hub rows, not the whole buffer)."""
     if force_zero:
         return _buf(shape, dev, True)
     out = _buf(shape, dev, False)
-    if wi.n_split > 0:
+    if wi.n_split > 0 and not DETERMINISTIC:
         out.index_fill_(0, wi.split_rows.long(), 0.0)
     return out
+
+
+def _part(wi, gkey):
+    """Partial-record buffer [n_slots, row stride of gkey] for the split keys of `wi`, or None."""
+    if not (DETERMINISTIC and wi.n_split > 0):
+        return None
+    return torch.empty((wi.n_slots, gkey.stride(0)), dtype=torch.float32, device=gkey.device)
+
+
+def _combine(wi, part, gkey, width, accumulate):
+    if part is not None:
+        _lib.call("disgat_seg_combine", wi.split_rows.data_ptr(), wi.split_ptr.data_ptr(), wi.n_split, width,
+                  part.data_ptr(), gkey.data_ptr(), gkey.stride(0), int(bool(accumulate)), ops._stream())
 
 
 def _seg_att3(wi, other, perm, g, lo, hi, H, f_out, keyop, otherop, a, n_keys, want_ga):
@@ -27,9 +46,11 @@ def _seg_att3(wi, other, perm, g, lo, hi, H, f_out, keyop, otherop, a, n_keys, w
     gkey = _keybuf((n_keys, H * f_out), dev, wi)
     n_waves = min(_MAX_WAVES, (wi.n_items + 3) // 4 * 4)
     ga_part = torch.empty((n_waves, H * f_out), dtype=torch.float32, device=dev) if want_ga else None
+    part = _part(wi, gkey)
     _lib.call("disgat_seg_grad_att3", wi.items.data_ptr(), wi.n_items, other.data_ptr(), ops._ptr(perm), g.data_ptr(),
               g.stride(0), lo, hi, H, f_out, keyop.data_ptr(), keyop.stride(0), otherop.data_ptr(), otherop.stride(0),
-              a.data_ptr(), gkey.data_ptr(), gkey.stride(0), ops._ptr(ga_part), n_waves, ops._stream())
+              a.data_ptr(), gkey.data_ptr(), gkey.stride(0), ops._ptr(ga_part), n_waves, ops._ptr(part), ops._stream())
+    _combine(wi, part, gkey, H * f_out, False)
     return gkey, (ga_part.sum(0) if want_ga else None)
 
 
@@ -40,16 +61,20 @@ def _seg_sign(wi, perm, g, lo, hi, H, f_out, sign, keyop, a, n_keys, want_ga, in
     gkey = _keybuf((n_keys, H * f_out), dev, wi) if into is None else into
     n_waves = min(_MAX_WAVES, (wi.n_items + 3) // 4 * 4)
     ga_part = torch.empty((n_waves, H * f_out), dtype=torch.float32, device=dev) if want_ga else None
+    part = _part(wi, gkey)
     _lib.call("disgat_seg_grad_sign", wi.items.data_ptr(), wi.n_items, ops._ptr(perm), g.data_ptr(), g.stride(0), lo, hi,
               H, f_out, sign.data_ptr(), keyop.data_ptr(), keyop.stride(0), a.data_ptr(), gkey.data_ptr(), gkey.stride(0),
-              ops._ptr(ga_part), n_waves, int(into is not None), ops._stream())
+              ops._ptr(ga_part), n_waves, int(into is not None), ops._ptr(part), ops._stream())
+    _combine(wi, part, gkey, H * f_out, into is not None)
     return gkey, (ga_part.sum(0) if want_ga else None)
 
 
 def _seg_hx(col_mode, wi, other, perm, coef, lo, hi, H, f, otherop, gkey, accumulate):
+    part = _part(wi, gkey)
     _lib.call("disgat_seg_grad_hx", int(col_mode), wi.items.data_ptr(), wi.n_items, other.data_ptr(), ops._ptr(perm),
               coef.data_ptr(), coef.stride(0), lo, hi, H, f, otherop.data_ptr(), otherop.stride(0), gkey.data_ptr(),
-              gkey.stride(0), int(accumulate), ops._stream())
+              gkey.stride(0), int(accumulate), ops._ptr(part), ops._stream())
+    _combine(wi, part, gkey, f if col_mode else H * f, accumulate)
 
 
 def edge_backward(ctx, gz, ge):
@@ -106,6 +131,12 @@ def edge_backward(ctx, gz, ge):
 
 
 _SEG_CACHE = {}          # (storage ptr, M, version, side, n_keys, chunk) -> (pairs kept alive, result); FIFO of 8
+
+
+def clear_segment_cache():
+    """Drop the memoised sorts / work items (each entry pins its pair list, an int32 permutation and the items: at
+    1M nodes several GB).  Pair lists are resampled every step, so Trainer._finish_step calls this after backward."""
+    _SEG_CACHE.clear()
 
 
 def _segments_of(pairs, side, n_keys, chunk):

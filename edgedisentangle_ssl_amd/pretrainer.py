@@ -9,13 +9,14 @@ side of the hot path:
     524-576); here the same distribution (Bernoulli(3*rho) over all entries united with a third
     of the positives, row-major order) is drawn in O(E) on the device (sampling.py);
   * `loss(...)` exposes the forward + loss part of train_step on pre-sampled pairs (what bench.py
-    times); train_step = sample + loss + backward + optimiser steps as in the reference.
+    times); train_step = sample + loss + backward + optimiser steps as in the reference;
+  * train_step returns its log values as 0-d DEVICE tensors (the reference calls .item() per step): nothing in a step
+    waits for the GPU except the sampler's output sizes; utils.resolve_logs() turns a dict of them into floats with
+    one transfer (main.run does that once per epoch).
 """
 import torch
 import torch.nn.functional as F
-import torch.optim as optim
-
-from . import ops, ops_gemm, parallel, sampling
+from . import ops, ops_bwd, ops_gemm, optim, parallel, sampling
 from .graph import graph_of
 from .layers import FuseLayer
 from .models import MLP
@@ -23,12 +24,11 @@ from .utils import adj_mse_loss, split
 
 
 def make_adam(params, args):
-    """The reference's per-module Adam (trainer.py:58-60) with torch's single-kernel (`fused`) step for device
-    parameters: a trainer owns 3-5 optimisers of a few tensors each and steps them all every train_step, which on
-    small graphs is mostly launch overhead."""
-    params = list(params)
-    fused = bool(params) and all(p.is_cuda for p in params)
-    return optim.Adam(params, lr=args.lr, weight_decay=args.weight_decay, **({"fused": True} if fused else {}))
+    """The reference's per-module Adam (trainer.py:58-60): same lr / weight_decay / betas / eps and independent state
+    per module, but every optimiser of a trainer is stepped by ONE multi-tensor HIP launch (optim.step_all) - a
+    trainer owns 3-5 optimisers of a few small tensors each and steps them all every train_step, which on small graphs
+    is mostly launch overhead."""
+    return optim.ModuleAdam(params, lr=args.lr, weight_decay=args.weight_decay)
 
 
 def _global_count(t, graph):
@@ -125,12 +125,12 @@ class Trainer(object):
             model.train()
             self.models_opt[i].zero_grad()
 
-    def _finish_step(self, loss, graph=None):
+    def _finish_step(self, loss, graph=None, always_step=False):
         (loss * self.loss_weight).backward()
+        ops_bwd.clear_segment_cache()              # the step's pair lists are not scored again
         parallel.all_reduce_grads(self.models, graph)
-        if self.loss_weight != 0:
-            for opt in self.models_opt:
-                opt.step()
+        if self.loss_weight != 0 or always_step:   # pretrainer.py:754-756 gates on the weight; trainer.py:205-206 does not
+            optim.step_all(self.models_opt)        # every sub-module's Adam in one launch
 
     def _layer_on(self, i):
         return self.constrain_layer == 0 or self.constrain_layer == i       # pretrainer.py:597, 728
@@ -202,7 +202,7 @@ class SupEdgeTrainer(Trainer):
         labels, indices = self.sample_train(gt_adj if gt_adj is not None else data[1])
         loss = self.loss(data, labels, indices)
         self._finish_step(loss, graph_of(data[1]))
-        return {"loss_heads_sup": loss.item()}
+        return {"loss_heads_sup": loss.detach()}
 
 
 class GeneratedEdgeTrainer(Trainer):
@@ -273,7 +273,7 @@ class GeneratedEdgeTrainer(Trainer):
         adj_labels, adj_masks = self.sample_train()
         loss = self.loss(data, adj_labels, adj_masks)
         self._finish_step(loss, graph_of(data[1]))
-        return {"loss_head_disen": loss.item()}
+        return {"loss_head_disen": loss.detach()}
 
 
 class DifHeadTrainer(Trainer):
@@ -367,4 +367,4 @@ class DifHeadTrainer(Trainer):
         self._begin_step()
         loss = self.loss(data)
         self._finish_step(loss, graph_of(data[1]))
-        return {"loss_head_diversity": loss.item()}
+        return {"loss_head_diversity": loss.detach()}

@@ -63,7 +63,9 @@ def sample_pairs(n_rows, pos_flat, generator=None, n_cols=None, n_pos_global=Non
     flat = torch.unique(torch.cat([rand_flat, pos_flat[sel]]))
     labels = membership(flat, pos_flat)
     rows = torch.div(flat, n_cols, rounding_mode="floor")
-    return torch.stack([rows, flat - rows * n_cols]), labels
+    idx = torch.stack([rows, flat - rows * n_cols])
+    idx._disgat_in_range = True          # in [0, n_rows) x [0, n_cols) by construction: ops.check_pairs skips it
+    return idx, labels
 
 
 def membership(flat, pos_flat):

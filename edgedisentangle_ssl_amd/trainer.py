@@ -3,6 +3,8 @@ trainer.py:16-32, 150-223, 297-320).  A caller of the hot path, kept for drop-in
 import torch
 import torch.nn.functional as F
 
+from . import parallel
+from .graph import graph_of
 from .models import MLP
 from .pretrainer import Trainer, make_adam
 from .utils import accuracy, split  # noqa: F401  (split re-exported: callers import it from here too)
@@ -41,6 +43,7 @@ class ClsTrainer(Trainer):
                               layers=args.cls_layer).to(dev)
         self.models.append(self.classifier)
         self.models_opt.append(make_adam(self.classifier.parameters(), args))
+        self.full_metrics = False
         tr, va, te, self.class_num_mat = split(labels.cpu(), train_ratio=args.node_sup_ratio)
         self.idx_train, self.idx_val, self.idx_test = tr.to(dev), va.to(dev), te.to(dev)
 
@@ -51,31 +54,63 @@ class ClsTrainer(Trainer):
         l1 = sum(p.abs().sum() for p in self.fuse1.parameters()) + sum(p.abs().sum() for p in self.fuse2.parameters())
         return self.args.reg_weight * l1
 
+    def _local(self, idx, graph):
+        """Node ids of `idx` (global) that this process owns, as local row ids, plus the global count."""
+        n_glob = int(idx.shape[0])
+        if isinstance(graph, parallel.DistGraph) and graph.world > 1:
+            lo = graph.row_start
+            keep = (idx >= lo) & (idx < lo + graph.n)
+            return idx[keep] - lo, idx[keep], n_glob
+        return idx, idx, n_glob
+
+    def _nll_acc(self, output, labels, idx, graph):
+        """F.nll_loss(output[idx], labels[idx]) and utils.accuracy over the GLOBAL index set (trainer.py:190-191): on a
+        row shard every rank sums over the nodes it owns and the sums are all-reduced; the loss value is global, its
+        gradient this rank's share (parameter gradients are summed over ranks afterwards)."""
+        loc, glob, n_glob = self._local(idx, graph)
+        lab = labels[glob]
+        logp = output[loc]
+        nll_sum = -logp.gather(1, lab.unsqueeze(1)).sum()
+        correct = (logp.argmax(1) == lab).sum().to(torch.float64)
+        if isinstance(graph, parallel.DistGraph) and graph.world > 1:
+            local = nll_sum / n_glob
+            tot = torch.stack([local.detach().to(torch.float64), correct])
+            parallel.all_reduce_sum(tot, graph)
+            return local + (tot[0].to(local.dtype) - local.detach()), tot[1] / n_glob
+        return nll_sum / n_glob, correct / n_glob
+
     def train_step(self, data, labels, epoch):
+        """trainer.py:178-223.  Log values are 0-d device tensors (utils.resolve_logs); the sklearn ROC / macro-F1 of
+        the validation split, which the reference recomputes on the host every step for its log line only, are
+        reported by test() and, when `full_metrics` is set, here too."""
         self._begin_step()
         feature, adj = data
+        graph = graph_of(adj)
+        sharded = isinstance(graph, parallel.DistGraph) and graph.world > 1
         output = self.classifier(self.get_em(feature, adj), cls=True)
-        loss_log = F.nll_loss(output[self.idx_train], labels[self.idx_train])
-        acc_train = accuracy(output[self.idx_train], labels[self.idx_train])
+        loss_log, acc_train = self._nll_acc(output, labels, self.idx_train, graph)
         reg_log = self.reg_fuser()
-        loss = loss_log + reg_log if self.args.reg else loss_log
-        (loss * self.loss_weight).backward()
-        for opt in self.models_opt:
-            opt.step()
+        loss = loss_log
+        if self.args.reg:          # the L1 term is replicated on every rank: each contributes 1/world of its gradient
+            loss = loss_log + (reg_log / graph.world if sharded else reg_log)
+        self._finish_step(loss, graph, always_step=True)
         with torch.no_grad():
-            loss_val = F.nll_loss(output[self.idx_val], labels[self.idx_val])
-            acc_val = accuracy(output[self.idx_val], labels[self.idx_val])
-        roc_val, f_val = roc_f(output[self.idx_val], labels[self.idx_val])
-        return {"loss_train": loss_log.item(), "acc_train": acc_train.item(), "loss_reg": reg_log.item(),
-                "loss_val": loss_val.item(), "acc_val": acc_val.item(), "roc_val": roc_val, "macroF_val": f_val}
+            loss_val, acc_val = self._nll_acc(output.detach(), labels, self.idx_val, graph)
+        log = {"loss_train": loss_log.detach(), "acc_train": acc_train, "loss_reg": reg_log.detach(),
+               "loss_val": loss_val, "acc_val": acc_val}
+        if self.full_metrics and not sharded:
+            log["roc_val"], log["macroF_val"] = roc_f(output[self.idx_val], labels[self.idx_val])
+        return log
 
     def test(self, data, labels, epoch=0):
         for m in self.models:
             m.eval()
         feature, adj = data
+        graph = graph_of(adj)
         with torch.no_grad():
             output = self.classifier(self.get_em(feature, adj), cls=True)
-            loss = F.nll_loss(output[self.idx_test], labels[self.idx_test])
-            acc = accuracy(output[self.idx_test], labels[self.idx_test])
+            loss, acc = self._nll_acc(output, labels, self.idx_test, graph)
+            if isinstance(graph, parallel.DistGraph) and graph.world > 1:
+                output = parallel.all_gather_rows(output, graph)      # the host metrics need every node's prediction
         roc, f1 = roc_f(output[self.idx_test], labels[self.idx_test])
         return {"loss_test": loss.item(), "acc_test": acc.item(), "roc_test": roc, "macroF_test": f1}

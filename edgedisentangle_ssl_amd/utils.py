@@ -118,3 +118,13 @@ def split(labels, train_ratio=0.25):
         test_idx += c_idx[a + b:a + b + c]
     random.shuffle(train_idx)
     return torch.LongTensor(train_idx), torch.LongTensor(val_idx), torch.LongTensor(test_idx), c_num_mat
+
+
+def resolve_logs(log):
+    """Dict with 0-d device tensors among its values -> plain Python numbers, ONE device-to-host transfer."""
+    keys = [k for k, v in log.items() if torch.is_tensor(v)]
+    if keys:
+        vals = torch.stack([log[k].detach().to(torch.float64).reshape(()) for k in keys]).tolist()
+        log = dict(log)
+        log.update(zip(keys, vals))
+    return log

@@ -30,6 +30,7 @@
  *  disgat_split_f16,    16-bit matrix cores (operand splitting), with the bias / additive / ELU (layers.py:508)
  *  disgat_amax,         / leaky-ReLU (layers.py:917, models.py:535) epilogues fused; weight preparation, the
  *  disgat_act_bwd       scale input and the activation's backward.
+ *  disgat_adam_multi    the per-sub-module torch.optim.Adam steps of a trainer (trainer.py:58-60, 205-206) as one launch.
  *
  * Layouts (all row-major fp32 unless noted; "ld*" = row stride in floats, a multiple of 4,
  * base pointers 16-byte aligned):
@@ -128,7 +129,7 @@ int disgat_bwd_alpha(const int32_t* items, int n_items, const int32_t* col, int6
 int disgat_seg_grad_att3(const int32_t* items, int n_items, const int32_t* other, const int32_t* perm,
                          const float* g, int64_t g_stride, int h_lo, int h_hi, int H, int F_out,
                          const float* keyop, int ld_key, const float* otherop, int ld_other, const float* a,
-                         float* gkey, int ld_gkey, float* ga_part, int n_waves, disgat_stream_t stream);
+                         float* gkey, int ld_gkey, float* ga_part, int n_waves, float* part, disgat_stream_t stream);
 
 /* The same gradient from the forward's sign record instead of a second operand gather (layout: sign_bits
  * above; row perm[m] of g and sign_bits belongs to list position m, NULL = identity):
@@ -141,14 +142,22 @@ int disgat_seg_grad_att3(const int32_t* items, int n_items, const int32_t* other
 int disgat_seg_grad_sign(const int32_t* items, int n_items, const int32_t* perm, const float* g,
                          int64_t g_stride, int h_lo, int h_hi, int H, int F_out, const uint32_t* sign_bits,
                          const float* keyop, int ld_key, const float* a, float* gkey, int ld_gkey,
-                         float* ga_part, int n_waves, int accumulate, disgat_stream_t stream);
+                         float* ga_part, int n_waves, int accumulate, float* part, disgat_stream_t stream);
 
 /* col_mode = 0: gkey[key][h][:] = sum_m coef[h][perm(m)] * otherop[other_m][:]          (F floats per row)
  * col_mode = 1: gkey[key][:] (+)= sum_m sum_h coef[h][perm(m)] * otherop[other_m][h][:]  (otherop rows H*F) */
 int disgat_seg_grad_hx(int col_mode, const int32_t* items, int n_items, const int32_t* other,
                        const int32_t* perm, const float* coef, int64_t coef_stride, int h_lo, int h_hi, int H,
                        int F, const float* otherop, int ld_other, float* gkey, int ld_gkey, int accumulate,
-                       disgat_stream_t stream);
+                       float* part, disgat_stream_t stream);
+
+/* Split keys (hub rows / columns cut into several work items, slot >= 0): when `part` ([n_slots][ld_gkey] floats) is
+ * given to the three segment launchers above, every slice stores its partial result in part[slot] instead of adding
+ * to gkey with float atomics, and this launcher then forms gkey[key][0:width] (+)= sum of the key's slices in slice
+ * order - run-to-run deterministic gradients.  split_keys [n_split], split_ptr [n_split+1] as in disgat_edge_combine.
+ * part == NULL in the launchers above keeps the atomic path (gkey rows of split keys must then be zeroed by the host). */
+int disgat_seg_combine(const int32_t* split_keys, const int32_t* split_ptr, int n_split, int width,
+                       const float* part, float* gkey, int ld_gkey, int accumulate, disgat_stream_t stream);
 
 /* ---- dense contractions --------------------------------------------------------------------- */
 
@@ -198,6 +207,21 @@ int disgat_split_f16(const float* W, int64_t stride_b, int64_t stride_k, int64_t
  * amax_out (or NULL): receives max |gin|, the scale input of the GEMMs that consume gin. */
 int disgat_act_bwd(const float* g, const float* out, float* gin, int64_t n, int act, float slope,
                    float* amax_out, disgat_stream_t stream);
+
+/* ---- optimiser --------------------------------------------------------------------------- */
+
+/* One Adam step for `count` parameter tensors in ONE launch per DISGAT_ADAM_MAX_TENSORS tensors (the table travels in
+ * the kernel arguments).  All arrays are HOST arrays of length count; params / grads / exp_avg / exp_avg_sq hold DEVICE
+ * pointers to numel[i] contiguous floats.  Per tensor: step_size = lr / (1 - beta1^t), inv_sqrt_bc2 = 1 / sqrt(1 -
+ * beta2^t), weight_decay (L2, added to the gradient) - t is that tensor's own step count, kept by the caller.
+ *   g += wd*p;  m += (g - m)(1 - beta1);  v = beta2 v + (1 - beta2) g^2;  p -= step_size * m / (sqrt(v)*inv_sqrt_bc2 + eps)
+ * Replaces the per-sub-module torch.optim.Adam steps of trainer.py:58-60, 205-206 and pretrainer.py:754-756, 633-635,
+ * 838-840 (same arithmetic as torch.optim.Adam, amsgrad off). */
+#define DISGAT_ADAM_MAX_TENSORS 64
+int disgat_adam_multi(int count, float* const* params, const float* const* grads, float* const* exp_avg,
+                      float* const* exp_avg_sq, const int64_t* numel, const float* step_size,
+                      const float* inv_sqrt_bc2, const float* weight_decay, float beta1, float beta2, float eps,
+                      disgat_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -267,7 +267,7 @@ def load_real(name):
     return processed_index_set(a), labels, feat, n
 
 
-def gen_real():
+def gen_real(skip_existing=False):
     # chameleon: cross-check my O(E) preprocessing against the reference loader itself
     import data_load as ref_dl
     cwd = os.getcwd()
@@ -293,7 +293,11 @@ def gen_real():
 
     for name, combos in (("cora", [(g, t) for g in GNNS for t in ATTS]),
                          ("chameleon", [(g, t) for g in GNNS for t in ATTS]),
-                         ("cora_full", [("AT", 3), ("SAGE", 1), ("GCN", 2)])):
+                         ("cora_full", [(g, t) for g in GNNS for t in ATTS])):
+        if skip_existing:
+            combos = [(g, t) for g, t in combos if not os.path.exists(os.path.join(GOLD, f"{name}_{g}_att{t}.npz"))]
+            if not combos:
+                continue
         idx, labels, feat, n = load_real(name)
         ei = torch.from_numpy(idx)
         lab = torch.from_numpy(labels)
@@ -327,6 +331,7 @@ def gen_real():
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
+    ap.add_argument("--skip-existing", action="store_true", help="real graphs: only (graph, gnn, att) fixtures not on disk yet")
     o = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
@@ -337,5 +342,5 @@ if __name__ == "__main__":
         if o.only in (None, "tiny"):
             gen_tiny()
         if o.only in (None, "real"):
-            gen_real()
+            gen_real(o.skip_existing)
         os.chdir(REPO)

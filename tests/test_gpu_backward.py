@@ -8,7 +8,7 @@ import pytest
 import torch
 
 import inputs_common as ic
-from test_gpu_parity import GNNS, ATTS, build, close, dev, make_args, real_inputs, tiny_inputs  # noqa: F401
+from test_gpu_parity import GNNS, ATTS, REAL, build, close, dev, make_args, real_inputs, tiny_inputs  # noqa: F401
 
 pytestmark = pytest.mark.gpu
 GTOL = 2e-4
@@ -90,6 +90,29 @@ def test_tiny_loss_gradients(golden_dir, dev, gnn, att, chunk, sign, monkeypatch
     _check(enc, g, "gdif.enc")
     for k, p in dif_t.classifier1.named_parameters():
         close(p.grad, g[f"gdif.cls1.{k}"], tol=GTOL, what=f"gdif.cls1.{k}")
+
+
+@pytest.mark.parametrize("name,gnn,att", REAL)
+def test_real_graph_ssl_losses(golden_dir, dev, name, gnn, att):
+    """BASELINE configs[1] ("SupEdge+DisEdge+DifHead SSL on"): the three loss values the unmodified reference's
+    train_step logged on Cora / chameleon / cora_full (pretrainer.py:612-627, 727-739, 819-832; recorded by
+    oracle/gen_golden.py with the same seeded pair lists), H = 8, nhid = 64, all 9 gnn_type x att combos."""
+    g = np.load(os.path.join(golden_dir, f"{name}_{gnn}_att{att}.npz"))
+    x, adj, n, ei, sup, ho, he = real_inputs(golden_dir, name, dev)
+    seed = 200 + att
+    a, enc, _ = build(gnn, att, 8, 64, x.shape[1], seed, dev)
+    sup_t, dis_t, dif_t = _trainers(a, enc, seed, dev)
+    data = (x, adj)
+    with torch.no_grad():
+        l_sup = sup_t.loss(data, sup[1].to(dev), [sup[0].to(dev)])
+        l_dis = dis_t.loss(data, [ho[1].to(dev), he[1].to(dev)], [ho[0].to(dev), he[0].to(dev)])
+        l_dif = dif_t.loss(data)
+    for key, got in (("loss_sup", l_sup), ("loss_dis", l_dis), ("loss_dif", l_dif)):
+        want = float(g[key])
+        assert abs(got.item() - want) <= 1e-5 * max(1.0, abs(want)), (name, gnn, att, key, got.item(), want)
+    # the same values with autograd recording (the training-mode kernels: sign record, merged layer pass)
+    l_sup_g = sup_t.loss(data, sup[1].to(dev), [sup[0].to(dev)])
+    assert abs(l_sup_g.item() - float(g["loss_sup"])) <= 2e-5 * max(1.0, abs(float(g["loss_sup"])))
 
 
 @pytest.mark.parametrize("gnn,att", [("AT", 3), ("SAGE", 2), ("GCN", 1), ("AT", 2), ("SAGE", 3)])

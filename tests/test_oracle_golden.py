@@ -198,3 +198,29 @@ def test_reference_sampler_properties(golden_dir):
     assert np.all(np.diff(mflat) > 0)
     assert mine_lab.sum() >= len(pos) // 3
     assert 0.5 < len(mflat) / len(flat) < 2.0
+
+
+@pytest.mark.parametrize("gnn,att", [("AT", 3), ("SAGE", 1)])
+def test_chameleon_losses(golden_dir, gnn, att):
+    """The oracle's three SSL losses on a REAL graph (chameleon, real features, H = 8, nhid = 64) against the values
+    the unmodified reference's train_step logged (pretrainer.py:612-627, 727-739, 819-832)."""
+    g = np.load(os.path.join(golden_dir, f"chameleon_{gnn}_att{att}.npz"))
+    d = np.load(os.path.join(golden_dir, "data_chameleon.npz"))
+    n = int(d["n"])
+    ei = torch.from_numpy(d["edge_index"].astype(np.int64))
+    lab = torch.from_numpy(d["labels"].astype(np.int64))
+    x = torch.from_numpy(d["features"])
+    pos, homo, het = ic.edge_sets(ei, lab, n)
+    sup = ic.sample_pairs(61, n, pos, "sup")
+    ho = ic.sample_pairs(62, n, homo, "homo")
+    he = ic.sample_pairs(63, n, het, "het")
+    H, nhid, seed = 8, 64, 200 + att
+    sd = ic.make_params(shapes_disgat(gnn, att, x.shape[1], nhid, H), seed)
+    with torch.no_grad():
+        r = orc.disgat_pass(sd, x, ei, fusers_from(seed, nhid, H), H, att, gnn, [sup[0]])
+        close(orc.sup_edge_loss(r["aux"], sup[1]), g["loss_sup"], rtol=1e-5, what="loss_sup")
+        r = orc.disgat_pass(sd, x, ei, fusers_from(seed, nhid, H), H, att, gnn, [ho[0], he[0]])
+        close(orc.dis_edge_loss(r["aux"], ho[1], he[1]), g["loss_dis"], rtol=1e-5, what="loss_dis")
+        c1 = ic.make_params(shapes_mlp(nhid + x.shape[1], nhid, H), seed + 4)
+        c2 = ic.make_params(shapes_mlp(2 * nhid, nhid, H), seed + 5)
+        close(orc.dif_head_loss(r["edge_em"], c1, c2), g["loss_dif"], rtol=1e-5, what="loss_dif")

@@ -86,18 +86,36 @@ def _worker(rank, world, port, q):
         q.put((rank, traceback.format_exc()))
 
 
-def test_row_sharding_world2():
+def _run_ranks(target, world, args=(), timeout=240):
+    import queue
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=target, args=(r, world, port, q) + tuple(args)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=240) for _ in procs]
-    for p in procs:
-        p.join(timeout=60)
+    res = []
+    try:
+        for _ in procs:
+            try:
+                res.append(q.get(timeout=timeout))
+            except queue.Empty:
+                break
+            if res[-1][1] != "ok":
+                break
+    finally:
+        for p in procs:
+            p.join(timeout=5 if (len(res) < world or any(m != "ok" for _, m in res)) else 60)
+            if p.is_alive():
+                p.kill()
+                p.join()
     for rank, msg in res:
         assert msg == "ok", f"rank {rank}:\n{msg}"
+    assert len(res) == world, f"only {len(res)} of {world} ranks reported (timeout)"
+
+
+def test_row_sharding_world2():
+    _run_ranks(_worker, 2)
 
 
 def test_balanced_ranges_skewed():
