@@ -311,6 +311,20 @@ def main():
     if world != o.gpus:
         raise SystemExit(f"--gpus {o.gpus} but WORLD_SIZE={world}")
     import torch.distributed as dist
+    if os.environ.get("DISGAT_BENCH_LAUNCH_PROBE") == "1":
+        # launcher self-test (tests/test_bench_launcher.py, no GPU): rendezvous over gloo, one collective, and the
+        # line rank 0 prints takes n_gpus from the process group - everything launch_ranks() is responsible for
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        t = torch.tensor([float(dist.get_rank())])
+        dist.all_reduce(t)
+        if dist.get_rank() == 0:
+            print(json.dumps({"probe": True, "n_gpus": dist.get_world_size(), "rank_sum": float(t), "scaling": o.scaling}))
+        dist.barrier()
+        dist.destroy_process_group()
+        if os.environ.get("DISGAT_BENCH_PROBE_FAIL_RANK") == str(rank):
+            raise SystemExit(3)
+        return
     # rehearsal on a one-GPU box: DISGAT_BENCH_REHEARSAL=1 puts every rank on cuda:0 over gloo
     rehearsal = os.environ.get("DISGAT_BENCH_REHEARSAL") == "1"
     if rehearsal:

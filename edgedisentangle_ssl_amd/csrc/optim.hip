@@ -24,7 +24,7 @@ struct AdamArgs {                   // passed by value in the kernel arguments (
   int count;
 };
 
-__global__ __launch_bounds__(256) void adam_multi_kernel(const AdamArgs a, float beta1, float beta2, float eps) {
+__global__ __launch_bounds__(256) void adam_multi_kernel(const AdamArgs a, float omb1, float beta2, float omb2, float eps) {
   // block -> tensor: binary search over <= 64 prefix entries (uniform per block: scalar registers)
   int lo = 0, hi = a.count;
   const int b = blockIdx.x;
@@ -40,7 +40,6 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const AdamArgs a, float
   float* __restrict__ m = a.m[t];
   float* __restrict__ v = a.v[t];
   const float ss = a.step_size[t], ib = a.inv_sqrt_bc2[t], wd = a.wd[t];
-  const float omb1 = 1.0f - beta1, omb2 = 1.0f - beta2;
   auto upd = [&](float& pw, float gw, float& mw, float& vw) {
     gw = fmaf(wd, pw, gw);                       // grad = grad + wd * param
     mw = mw + (gw - mw) * omb1;                  // exp_avg.lerp_(grad, 1 - beta1)
@@ -82,9 +81,10 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const AdamArgs a, float
 
 extern "C" int disgat_adam_multi(int count, float* const* params, const float* const* grads, float* const* exp_avg,
                                  float* const* exp_avg_sq, const int64_t* numel, const float* step_size,
-                                 const float* inv_sqrt_bc2, const float* weight_decay, float beta1, float beta2,
+                                 const float* inv_sqrt_bc2, const float* weight_decay, double beta1, double beta2,
                                  float eps, disgat_stream_t stream) {
   DISGAT_REQUIRE(count >= 0, "adam_multi: negative tensor count");
+  const double beta1_d = beta1, beta2_d = beta2;
   for (int off = 0; off < count; off += kMaxTensors) {
     AdamArgs a;
     a.count = count - off < kMaxTensors ? count - off : kMaxTensors;
@@ -107,7 +107,9 @@ extern "C" int disgat_adam_multi(int count, float* const* params, const float* c
     }
     a.first_block[a.count] = blocks;
     if (blocks == 0) continue;
-    hipLaunchKernelGGL(adam_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, beta1, beta2, eps);
+    // 1 - beta in double, as torch forms the lerp / addcmul weights (1.0f - 0.999f is off by 1.3e-5 relative)
+    hipLaunchKernelGGL(adam_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, (float)(1.0 - (double)beta1_d),
+                       (float)beta2_d, (float)(1.0 - beta2_d), eps);
     if (int rc = disgat::check_launch("adam_multi")) return rc;
   }
   return 0;

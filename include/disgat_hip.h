@@ -220,7 +220,7 @@ int disgat_act_bwd(const float* g, const float* out, float* gin, int64_t n, int 
 #define DISGAT_ADAM_MAX_TENSORS 64
 int disgat_adam_multi(int count, float* const* params, const float* const* grads, float* const* exp_avg,
                       float* const* exp_avg_sq, const int64_t* numel, const float* step_size,
-                      const float* inv_sqrt_bc2, const float* weight_decay, float beta1, float beta2, float eps,
+                      const float* inv_sqrt_bc2, const float* weight_decay, double beta1, double beta2, float eps,
                       disgat_stream_t stream);
 
 #ifdef __cplusplus

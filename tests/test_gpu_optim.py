@@ -40,8 +40,8 @@ def test_multi_adam_matches_torch_adam():
         st = r_opts[[i for i, (a, b) in enumerate(cuts) if a <= k < b][0]].state[q]
         mine = o_opts[[i for i, (a, b) in enumerate(cuts) if a <= k < b][0]].state[id(p)]
         assert int(st["step"]) == mine[0]
-        assert torch.allclose(mine[1], st["exp_avg"], rtol=1e-5, atol=1e-9)
-        assert torch.allclose(mine[2], st["exp_avg_sq"], rtol=1e-5, atol=1e-12)
+        for got, want in ((mine[1], st["exp_avg"]), (mine[2], st["exp_avg_sq"])):     # a few ulp of the tensor's scale
+            assert (got - want).abs().max().item() <= 2e-6 * want.abs().max().item(), k
 
 
 def test_multi_adam_many_tensors_and_state_dict():
