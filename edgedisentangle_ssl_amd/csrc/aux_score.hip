@@ -30,8 +30,9 @@ struct AuxArgs {
   uint32_t* sign;   // att 3, optional: [M][64] sign words for the backward pass (disgat_common.h)
 };
 
-// att 3: lane = (head, g) exactly as in edge_fwd_kernel<3,...>.
-template <int HL, int QN, bool SIGN>
+// att 3: lane = (head, g) exactly as in edge_fwd_kernel<3,...>.  DOT = att 4 (att 2 over the per-head projected
+// operands, layers.py:362-365): e = <P[row][h][:], Q[col][h][:]>, same lane map, no `a`, no nonlinearity.
+template <int HL, int QN, bool SIGN, bool DOT = false>
 __global__ __launch_bounds__(DISGAT_BLOCK, 2) void aux_att3_kernel(const AuxArgs A) {
   constexpr int GL = 6 - HL;
   constexpr int G = 1 << GL;
@@ -49,7 +50,7 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void aux_att3_kernel(const AuxArgs
   f32x4 a_r[QN], p_r[QN], qA[QN], qB[QN];
 #pragma unroll
   for (int j = 0; j < QN; ++j) {
-    a_r[j] = active ? ld4(A.a + qoff + j * G * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    a_r[j] = (active && !DOT) ? ld4(A.a + qoff + j * G * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
     p_r[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   int cur_r = -1;
@@ -80,7 +81,10 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void aux_att3_kernel(const AuxArgs
       }
     }
     float acc = 0.f;
-    if constexpr (SIGN) {
+    if constexpr (DOT) {
+#pragma unroll
+      for (int j = 0; j < QN; ++j) acc = dot4(p_r[j], q[j], acc);
+    } else if constexpr (SIGN) {
       SignAcc sg;
 #pragma unroll
       for (int j = 0; j < QN; ++j) acc = dot4_lrelu_sign(a_r[j], p_r[j], q[j], acc, sg);
@@ -275,13 +279,13 @@ __global__ __launch_bounds__(256) void pair_loss_bwd_kernel(const float* __restr
 
 namespace disgat {
 
-template <int HL, bool SIGN>
+template <int HL, bool SIGN, bool DOT = false>
 static int launch_aux3(int qn, const AuxArgs& A, int grid, hipStream_t s) {
   switch (qn) {
-    case 1: hipLaunchKernelGGL((aux_att3_kernel<HL, 1, SIGN>), dim3(grid), dim3(DISGAT_BLOCK), 0, s, A); break;
-    case 2: hipLaunchKernelGGL((aux_att3_kernel<HL, 2, SIGN>), dim3(grid), dim3(DISGAT_BLOCK), 0, s, A); break;
-    case 4: hipLaunchKernelGGL((aux_att3_kernel<HL, 4, SIGN>), dim3(grid), dim3(DISGAT_BLOCK), 0, s, A); break;
-    case 8: hipLaunchKernelGGL((aux_att3_kernel<HL, 8, SIGN>), dim3(grid), dim3(DISGAT_BLOCK), 0, s, A); break;
+    case 1: hipLaunchKernelGGL((aux_att3_kernel<HL, 1, SIGN, DOT>), dim3(grid), dim3(DISGAT_BLOCK), 0, s, A); break;
+    case 2: hipLaunchKernelGGL((aux_att3_kernel<HL, 2, SIGN, DOT>), dim3(grid), dim3(DISGAT_BLOCK), 0, s, A); break;
+    case 4: hipLaunchKernelGGL((aux_att3_kernel<HL, 4, SIGN, DOT>), dim3(grid), dim3(DISGAT_BLOCK), 0, s, A); break;
+    case 8: hipLaunchKernelGGL((aux_att3_kernel<HL, 8, SIGN, DOT>), dim3(grid), dim3(DISGAT_BLOCK), 0, s, A); break;
     default: return fail(-2, "aux_score att=3: F_out must be QN*(64/H)*4 with QN in {1,2,4,8}");
   }
   return check_launch("aux_att3_kernel");
@@ -306,7 +310,7 @@ extern "C" int disgat_aux_score(int att, const int64_t* pair_rows, const int64_t
                                 int ld_row, const float* colop, int ld_col, const float* a, float* out,
                                 uint32_t* sign_bits, disgat_stream_t stream) {
   using namespace disgat;
-  DISGAT_REQUIRE(att >= 1 && att <= 3, "aux_score: att=%d not in 1..3", att);
+  DISGAT_REQUIRE(att >= 1 && att <= 4, "aux_score: att=%d not in 1..3 (4 = att 2 over projected operands)", att);
   DISGAT_REQUIRE(M >= 0 && N > 0, "aux_score: bad sizes");
   if (M == 0 || h_lo >= h_hi) return 0;
   const int hl = ilog2_exact(H);
@@ -342,10 +346,18 @@ extern "C" int disgat_aux_score(int att, const int64_t* pair_rows, const int64_t
   }
   const int g4 = (64 >> hl) * 4;
   DISGAT_REQUIRE(F_out > 0 && F_out % g4 == 0, "aux_score att=3: F_out=%d must be a multiple of %d", F_out, g4);
-  DISGAT_REQUIRE(colop && a && ld_row % 4 == 0 && ld_col % 4 == 0 && ld_row >= H * F_out && ld_col >= H * F_out &&
-                     aligned16(rowop) && aligned16(colop) && aligned16(a),
+  DISGAT_REQUIRE(colop && (a || att == 4) && ld_row % 4 == 0 && ld_col % 4 == 0 && ld_row >= H * F_out && ld_col >= H * F_out &&
+                     aligned16(rowop) && aligned16(colop) && (att == 4 || aligned16(a)),
                  "aux_score att=3: bad P/Q strides or alignment");
   const int qn = F_out / g4;
+  if (att == 4) {
+    switch (hl) {
+      case 1: return launch_aux3<1, false, true>(qn, A, grid, s);
+      case 2: return launch_aux3<2, false, true>(qn, A, grid, s);
+      case 3: return launch_aux3<3, false, true>(qn, A, grid, s);
+      default: return launch_aux3<4, false, true>(qn, A, grid, s);
+    }
+  }
   if (A.sign != nullptr) {
     switch (hl) {
       case 1: return launch_aux3<1, true>(qn, A, grid, s);

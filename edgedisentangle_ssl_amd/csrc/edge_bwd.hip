@@ -184,7 +184,8 @@ struct SegArgs {
   float* part;           // [n_slots][ld_gkey] partial records of split keys, or null (atomics)
 };
 
-template <int HL, int QN>
+// DOT (att 4: e = <keyop[key], otherop[other]> per head, no `a`): gkey[key] = sum_m g_m * otherop[other_m].
+template <int HL, int QN, bool DOT = false>
 __global__ __launch_bounds__(DISGAT_BLOCK, 2) void seg_grad_att3_kernel(const SegArgs A) {
   constexpr int GL = 6 - HL;
   constexpr int G = 1 << GL;
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void seg_grad_att3_kernel(const Se
   f32x4 a_r[QN], ga[QN];
 #pragma unroll
   for (int j = 0; j < QN; ++j) {
-    a_r[j] = ld4(A.a + qoff + j * G * 4);
+    a_r[j] = DOT ? f32x4{0.f, 0.f, 0.f, 0.f} : ld4(A.a + qoff + j * G * 4);
     ga[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
@@ -225,6 +226,11 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void seg_grad_att3_kernel(const Se
     auto compute = [&](const f32x4(&q)[QN], int gpos) {
       if (active) {
         const float gv = A.g[(int64_t)myh * A.g_stride + gpos];
+        if constexpr (DOT) {
+#pragma unroll
+          for (int j = 0; j < QN; ++j) gk[j] += gv * q[j];
+          return;
+        }
 #pragma unroll
         for (int j = 0; j < QN; ++j) {
           const f32x4 z = p_r[j] + q[j];
@@ -553,14 +559,19 @@ extern "C" int disgat_seg_grad_att3(const int32_t* items, int n_items, const int
   if (int rc = seg_common_checks("seg_grad_att3", items, n_items, other, g, H, h_lo, h_hi, otherop, gkey)) return rc;
   const int hl = ilog2_exact(H);
   const int g4 = (64 >> hl) * 4;
-  DISGAT_REQUIRE(F_out > 0 && F_out % g4 == 0 && keyop && a, "seg_grad_att3: bad F_out=%d", F_out);
+  DISGAT_REQUIRE(F_out > 0 && F_out % g4 == 0 && keyop, "seg_grad_att3: bad F_out=%d", F_out);
+  DISGAT_REQUIRE(a != nullptr || ga_part == nullptr, "seg_grad_att3: a == NULL selects the plain dot-product score (att 4), which has no `a` gradient");
   DISGAT_REQUIRE(n_waves > 0 && n_waves % DISGAT_WAVES_PER_BLOCK == 0, "seg_grad_att3: n_waves must be a positive multiple of %d", DISGAT_WAVES_PER_BLOCK);
   const int qn = F_out / g4;
   SegArgs A{reinterpret_cast<const int4*>(items), n_items, other, perm, g, g_stride, h_lo, h_hi, F_out, keyop, ld_key,
             otherop, ld_other, a, gkey, ld_gkey, ga_part, 0, part};
   const dim3 grid(n_waves / DISGAT_WAVES_PER_BLOCK), block(DISGAT_BLOCK);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-#define DISGAT_SG(HL_, QN_) hipLaunchKernelGGL((seg_grad_att3_kernel<HL_, QN_>), grid, block, 0, s, A)
+#define DISGAT_SG(HL_, QN_)                                                                     \
+  do {                                                                                          \
+    if (a) hipLaunchKernelGGL((seg_grad_att3_kernel<HL_, QN_, false>), grid, block, 0, s, A);  \
+    else hipLaunchKernelGGL((seg_grad_att3_kernel<HL_, QN_, true>), grid, block, 0, s, A);     \
+  } while (0)
 #define DISGAT_SGQ(HL_)                                                                       \
   switch (qn) {                                                                               \
     case 1: DISGAT_SG(HL_, 1); break;                                                         \

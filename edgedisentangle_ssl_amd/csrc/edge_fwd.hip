@@ -20,6 +20,10 @@
 //   att 2: x[col] and P[row][h][:] coalesced (lane*4 floats); the H per-head dot products are
 //          reduced together by one transposed butterfly (multi_reduce) into the same head groups.
 //   att 1: score head of a lane = lane % H, s2[col][h] gathered directly.
+//   att 4: att 2 in the reference's own formulation (layers.py:362-365): e = <h[row][h][:], h[col][h][:]> with
+//          h = x W per head - the dot product runs over F_out instead of F_in, so the layer input may be arbitrarily
+//          wide (raw bag-of-words features, --origin_feat); lane map, operand layout and padding of att 3
+//          (rowop = colop = h [N][H*F_out]), no `a`, no nonlinearity.
 #include "disgat_common.h"
 
 namespace disgat {
@@ -49,7 +53,7 @@ struct EdgeFwdArgs {
 
 template <int ATT, int HL, int QN, int XN>
 struct ColBuf {
-  f32x4 q[ATT == 3 ? QN : 1];
+  f32x4 q[(ATT == 3 || ATT == 4) ? QN : 1];
   f32x4 xv[XN];
   float s2;
 };
@@ -69,20 +73,21 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void edge_fwd_kernel(const EdgeFwd
   // which head this lane scores, and which lane to read head hh's weight from
   // att 2/3: head group = lane / G (the layout the multi-value reduction / the DPP group sums leave
   // the scores in); att 1: head = lane % H (scores are gathered directly per lane)
+  constexpr bool PQ = (ATT == 3 || ATT == 4);       // per-head projected operands on both sides (att-3 lane map)
   const int myh = (ATT != 1) ? (lane >> GL) : (lane & (H - 1));
   auto head_lane = [](int hh) { return (ATT != 1) ? (hh << GL) : hh; };
   const int xoff = lane * 4;
-  const int qoff = (ATT == 3) ? (myh * FQ + (lane & (G - 1)) * 4) : 0;
+  const int qoff = PQ ? (myh * FQ + (lane & (G - 1)) * 4) : 0;
 
   // ---- row-side operands (once per work item)
   f32x4 a_r[ATT == 3 ? QN : 1];
-  f32x4 p_r[ATT == 3 ? QN : (ATT == 2 ? H * XN : 1)];
+  f32x4 p_r[PQ ? QN : (ATT == 2 ? H * XN : 1)];
   float s1r = 0.f;
-  if constexpr (ATT == 3) {
+  if constexpr (PQ) {
     const float* pp = A.rowop + (size_t)row * A.ld_row + qoff;
 #pragma unroll
     for (int j = 0; j < QN; ++j) {
-      a_r[j] = ld4(A.a + qoff + j * G * 4);
+      if constexpr (ATT == 3) a_r[j] = ld4(A.a + qoff + j * G * 4);
       p_r[j] = ld4(pp + j * G * 4);
     }
   } else if constexpr (ATT == 2) {
@@ -107,7 +112,7 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void edge_fwd_kernel(const EdgeFwd
   using Buf = ColBuf<ATT, HL, QN, XN>;
 
   auto load_edge = [&](Buf& b, int c) {
-    if constexpr (ATT == 3) {
+    if constexpr (PQ) {
       const float* qp = A.colop + (size_t)c * A.ld_col + qoff;
 #pragma unroll
       for (int j = 0; j < QN; ++j) b.q[j] = ld4(qp + j * G * 4);
@@ -139,6 +144,11 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void edge_fwd_kernel(const EdgeFwd
       float acc = 0.f;
 #pragma unroll
       for (int j = 0; j < QN; ++j) acc = dot4_lrelu(a_r[j], p_r[j], b.q[j], acc);
+      e = group_sum<GL>(acc);
+    } else if constexpr (ATT == 4) {
+      float acc = 0.f;
+#pragma unroll
+      for (int j = 0; j < QN; ++j) acc = dot4(p_r[j], b.q[j], acc);
       e = group_sum<GL>(acc);
     } else if constexpr (ATT == 2) {
       float part[H];
@@ -297,13 +307,13 @@ static int launch_edge_x(int xn, const EdgeFwdArgs& args, hipStream_t stream) {
 
 template <int ATT, int HL>
 static int launch_edge_q(int qn, int xn, const EdgeFwdArgs& args, hipStream_t stream) {
-  if constexpr (ATT == 3) {
+  if constexpr (ATT == 3 || ATT == 4) {
     switch (qn) {
-      case 1: return launch_edge_x<3, HL, 1>(xn, args, stream);
-      case 2: return launch_edge_x<3, HL, 2>(xn, args, stream);
-      case 4: return launch_edge_x<3, HL, 4>(xn, args, stream);
-      case 8: return launch_edge_x<3, HL, 8>(xn, args, stream);
-      default: return fail(-2, "edge_fwd att=3: F_out must be QN*(64/H)*4 with QN in {1,2,4,8}");
+      case 1: return launch_edge_x<ATT, HL, 1>(xn, args, stream);
+      case 2: return launch_edge_x<ATT, HL, 2>(xn, args, stream);
+      case 4: return launch_edge_x<ATT, HL, 4>(xn, args, stream);
+      case 8: return launch_edge_x<ATT, HL, 8>(xn, args, stream);
+      default: return fail(-2, "edge_fwd att=3/4: F_out must be QN*(64/H)*4 with QN in {1,2,4,8}");
     }
   } else {
     return launch_edge_x<ATT, HL, 1>(xn, args, stream);
@@ -329,7 +339,7 @@ extern "C" int disgat_edge_fwd(int att, const int32_t* items, int n_items, const
                                float* part_z, float* part_den, int sage_div, float drop_p, uint64_t drop_seed,
                                uint32_t* sign_bits, disgat_stream_t stream) {
   using namespace disgat;
-  DISGAT_REQUIRE(att >= 1 && att <= 3, "edge_fwd: att=%d not in 1..3", att);
+  DISGAT_REQUIRE(att >= 1 && att <= 4, "edge_fwd: att=%d not in 1..3 (4 = att 2 over projected operands)", att);
   DISGAT_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "edge_fwd: dropout p=%f outside [0,1)", (double)drop_p);
   DISGAT_REQUIRE(n_items >= 0 && N > 0 && E >= 0, "edge_fwd: bad sizes n_items=%d N=%d E=%lld", n_items, N, (long long)E);
   if (n_items == 0) return 0;
@@ -340,13 +350,13 @@ extern "C" int disgat_edge_fwd(int att, const int32_t* items, int n_items, const
   DISGAT_REQUIRE(aligned16(items) && aligned16(x) && aligned16(Z), "edge_fwd: items/x/Z must be 16-byte aligned");
   const int xn = (F_in + 255) / 256;
   int qn = 1;
-  if (att == 3) {
+  if (att == 3 || att == 4) {
     const int g4 = (64 >> hl) * 4;
     DISGAT_REQUIRE(F_out > 0 && F_out % g4 == 0, "edge_fwd att=3: F_out=%d must be a multiple of %d", F_out, g4);
     qn = F_out / g4;
-    DISGAT_REQUIRE(colop && a && ld_row % 4 == 0 && ld_col % 4 == 0 && ld_row >= H * F_out && ld_col >= H * F_out,
+    DISGAT_REQUIRE(colop && (a || att == 4) && ld_row % 4 == 0 && ld_col % 4 == 0 && ld_row >= H * F_out && ld_col >= H * F_out,
                    "edge_fwd att=3: bad P/Q strides");
-    DISGAT_REQUIRE(aligned16(rowop) && aligned16(colop) && aligned16(a), "edge_fwd att=3: P/Q/a must be 16-byte aligned");
+    DISGAT_REQUIRE(aligned16(rowop) && aligned16(colop) && (att == 4 || aligned16(a)), "edge_fwd att=3: P/Q/a must be 16-byte aligned");
   } else if (att == 2) {
     DISGAT_REQUIRE(ld_row % 4 == 0 && ld_row >= H * F_in && aligned16(rowop), "edge_fwd att=2: bad P stride/alignment");
   } else {
@@ -360,6 +370,7 @@ extern "C" int disgat_edge_fwd(int att, const int32_t* items, int n_items, const
   switch (att) {
     case 1: return launch_edge_h<1>(hl, qn, xn, args, s);
     case 2: return launch_edge_h<2>(hl, qn, xn, args, s);
+    case 4: return launch_edge_h<4>(hl, qn, xn, args, s);
     default: return launch_edge_h<3>(hl, qn, xn, args, s);
   }
 }

@@ -132,7 +132,7 @@ def _kernel_heads(att, Hp, f_out, f_in_p=0):
     if att == 2:                                    # the dot product over x cannot be sliced: fewer heads per
         while hk > 2 and 256 * (16 // hk) < min(f_in_p, 512):   # launch buy a wider register tile instead
             hk //= 2
-    if att != 3:
+    if att not in (3, 4):
         return hk, f_out
     while hk >= 2:
         g4 = (64 // hk) * 4
@@ -140,7 +140,7 @@ def _kernel_heads(att, Hp, f_out, f_in_p=0):
         if qn <= 8:
             return hk, qn * g4
         hk //= 2
-    raise NotImplementedError(f"att=3 kernel envelope: a single head wider than 1024 features (nhid={f_out})")
+    raise NotImplementedError(f"att={att} kernel envelope: a single head wider than 1024 features (nhid={f_out})")
 
 
 def _memo(layers, tag, build):
@@ -175,6 +175,8 @@ def _pack_score_operands(layers, x, x_all, att, H, Hp, f_in, f_out, fp, am=None)
     att 1 (layers.py:349-353):  e = [h_r || h_c] . a,  h = x W   ==  s1[r] + s2[c]
                                 with s1 = x (W a[:F]),  s2 = x (W a[F:])           -> [N,Hp] each
     att 2 (layers.py:362-365):  e = <x_r W, x_c W> = <x_r (W W^T), x_c>           -> P = x (W W^T)
+    att 4 (= att 2 for inputs wider than the att-2 register tile): the same score from h = x W on both
+                                sides, e = <h[r][h], h[c][h]>                      -> [N,Hp*fp], att-3 layout
     att 3 (layers.py:374-379):  e = a . lrelu([x_r || x_c] W) = a . lrelu(P[r] + Q[c]),
                                 P = x W[:F_in], Q = x W[F_in:]                     -> [N,Hp*fp] each
     Returns (rowop, colop, a_vec); fp = padded per-head width of the att-3 operands.  am: max |x_all| as a device
@@ -185,6 +187,17 @@ def _pack_score_operands(layers, x, x_all, att, H, Hp, f_in, f_out, fp, am=None)
         w1 = torch.stack([l.W @ l.a[:f_out, 0] for l in layers] + zero, dim=1)     # [F_in, Hp]
         w2 = torch.stack([l.W @ l.a[f_out:, 0] for l in layers] + zero, dim=1)
         return x @ w1, x_all @ w2, None                                            # N = Hp: too narrow for the MFMA tile
+    if att == 4:
+        # att 2 as the reference writes it (layers.py:362-365): h = x W per head, e = <h[r], h[c]>.  One operand table
+        # serves both sides (column ids index the gathered x_all; unsharded, x_all is x and the GEMM runs once).
+        def pack4():
+            wc = torch.cat([F.pad(l.W, (0, fp - f_out)) for l in layers] + [x.new_zeros(f_in, fp)] * (Hp - H), dim=1)
+            return wc, ops_gemm.presplit(wc)
+
+        wc, sc = _memo(layers, ("att4", fp, Hp), pack4)
+        hcol = ops_gemm.linear(x_all, wc, a_amax=am, w_split=sc)
+        hrow = hcol if x_all is x else ops_gemm.linear(x, wc, a_amax=am, w_split=sc)
+        return hrow, hcol, None
     if att == 2:
         f_in_p = (f_in + 3) // 4 * 4
         ms = [F.pad(l.W @ l.W.t(), (0, f_in_p - f_in)) for l in layers]
@@ -229,6 +242,12 @@ def disga_heads(layers, x, adj, aux_indices=None, head_ranges=None, aux_only=Fal
         raise ValueError("adjacency / feature row count mismatch")
     Hp = max(2, _pow2ceil(H))
     f_in_p = (f_in + 3) // 4 * 4
+    if att == 2 and f_in_p > 512:
+        # att 2's fused form dots P[r] = x_r (W W^T) with the gathered x[c] over all F_in columns held in registers
+        # (F_in <= 512).  Wider inputs (raw bag-of-words features, --origin_feat: Cora 1 433) take the reference's
+        # own formulation instead: per-head projections h = x W on both sides (kernel code 4), x aggregated in
+        # column slices like att 1 / 3.
+        att = 4
     Hk, fp = _kernel_heads(att, Hp, f_out, f_in_p)   # heads per launch; Hp / Hk head groups
     n_groups = Hp // Hk
     # register tile of the edge pass: Hk * ceil(F_in/256) float4 accumulators <= 16.  Wider inputs (raw
@@ -236,8 +255,7 @@ def disga_heads(layers, x, adj, aux_indices=None, head_ranges=None, aux_only=Fal
     # not depend on x, so every slice sees identical attention weights (the scores are recomputed per
     # slice: correct, not cheap).  att 2's score is a dot product over all of x and cannot be sliced.
     tile = min(512, 256 * max(1, 16 // Hk))
-    if f_in_p > tile and att == 2:
-        raise NotImplementedError(f"kernel envelope: att=2 needs F_in <= {tile} with {Hk} heads per launch (got {f_in})")
+    assert not (att == 2 and f_in_p > tile), "att 2 wider than its register tile is routed to the projected form above"
     x_all = parallel.all_gather_rows(x, graph)       # sharded: one exchange per layer
     xg = x_all if (f_in_p == f_in and x_all.is_contiguous()) else F.pad(x_all, (0, f_in_p - f_in)).contiguous()
 
@@ -250,7 +268,7 @@ def disga_heads(layers, x, adj, aux_indices=None, head_ranges=None, aux_only=Fal
     z_bound = None if am_x is None else am_x * (1.001 / (1.0 - drop[0]))
     rowop, colop, a_vec = _pack_score_operands(layers, x, x_all, att, H, Hp, f_in, f_out, fp, am_x)
     # per-head operand width inside a row of rowop / colop (att 1: one scalar, att 2: F_in_p, att 3: fp)
-    w_row = {1: 1, 2: f_in_p, 3: fp}[att]
+    w_row = {1: 1, 2: f_in_p, 3: fp, 4: fp}[att]
 
     def group_ops(gi):
         lo = gi * Hk * w_row

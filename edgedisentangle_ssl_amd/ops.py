@@ -11,7 +11,7 @@ from .graph import CSRGraph
 
 # max edges per work item, by attention type: bounds the tail on power-law rows while keeping
 # the partial-record traffic (H*F_in floats per chunk) small next to the chunk's gather bytes.
-CHUNK = {1: 256, 2: 256, 3: 128}
+CHUNK = {1: 256, 2: 256, 3: 128, 4: 128}
 
 
 # bench.py sets PROFILE to a list: every launch is then bracketed by HIP events recorded on the
@@ -35,13 +35,13 @@ def edge_algorithmic_bytes(att, n, e, H, F_in, F_out):
     """SURVEY 8(d) B_layer: col index + neighbour row + column-side score operand + edge_e store per
     edge; layer input read once + per-head output written once per node; rowptr.  (att 2 gathers no
     column-side operand in this dataflow: S = 0.)"""
-    s = {1: H, 2: 0, 3: H * F_out}[att]
+    s = {1: H, 2: 0, 3: H * F_out, 4: H * F_out}[att]
     return e * (4 + 4 * F_in + 4 * s + 4 * H) + n * (4 * F_in + 4 * H * F_out) + 4 * (n + 1)
 
 
 def aux_algorithmic_bytes(att, n, m, nheads, F_in, F_out):
     """SURVEY 8(d) B_aux: index pair + column-side operand per pair; row-side operand once per node."""
-    s = {1: nheads, 2: F_in, 3: nheads * F_out}[att]
+    s = {1: nheads, 2: F_in, 3: nheads * F_out, 4: nheads * F_out}[att]
     return m * (8 + 4 * s) + n * 4 * s
 
 

@@ -49,7 +49,7 @@ def _seg_att3(wi, other, perm, g, lo, hi, H, f_out, keyop, otherop, a, n_keys, w
     part = _part(wi, gkey)
     _lib.call("disgat_seg_grad_att3", wi.items.data_ptr(), wi.n_items, other.data_ptr(), ops._ptr(perm), g.data_ptr(),
               g.stride(0), lo, hi, H, f_out, keyop.data_ptr(), keyop.stride(0), otherop.data_ptr(), otherop.stride(0),
-              a.data_ptr(), gkey.data_ptr(), gkey.stride(0), ops._ptr(ga_part), n_waves, ops._ptr(part), ops._stream())
+              ops._ptr(a), gkey.data_ptr(), gkey.stride(0), ops._ptr(ga_part), n_waves, ops._ptr(part), ops._stream())
     _combine(wi, part, gkey, H * f_out, False)
     return gkey, (ga_part.sum(0) if want_ga else None)
 
@@ -97,7 +97,7 @@ def edge_backward(ctx, gz, ge):
     g_x = g_row = g_col = g_a = None
     t = twi = None
     sign = getattr(ctx, "sign", None)
-    if need_x or (att == 3 and (need_col or (need_a and sign is not None))):
+    if need_x or (att == 4 and need_col) or (att == 3 and (need_col or (need_a and sign is not None))):
         t = graph.transpose()
         twi = t.work_items(chunk)
     if att == 1:
@@ -110,6 +110,11 @@ def edge_backward(ctx, gz, ge):
         if need_row:                                    # gP[r,h,:] = sum_k ge_k x[col_k]
             g_row = _keybuf((n, H * f_in), dev, wi)
             _seg_hx(0, wi, graph.col, None, ge_tot, 0, H, H, f_in, x, g_row, False)
+    elif att == 4:                                      # e = <h[r], h[c]> per head: gP[r] = sum ge h[c], gQ[c] = sum ge h[r]
+        if need_row:
+            g_row, _ = _seg_att3(wi, graph.col, None, ge_tot, 0, H, H, f_out, rowop, colop, None, n, False)
+        if need_col:
+            g_col, _ = _seg_att3(twi, t.col, t.eid, ge_tot, 0, H, H, f_out, colop, rowop, None, colop.shape[0], False)
     elif sign is not None:                              # gather-free: both sides read the sign record
         if need_row or need_a:
             g_row, g_a = _seg_sign(wi, None, ge_tot, 0, H, H, f_out, sign, rowop, a, n, need_a)
@@ -188,7 +193,7 @@ def aux_backward(ctx, gout):
         return g_x, g_row, g_col, g_a, None, None
     chunk = ops.CHUNK[att]
     n_rows = rowop.shape[0]
-    n_cols = colop.shape[0] if att == 3 else x.shape[0]
+    n_cols = colop.shape[0] if att in (3, 4) else x.shape[0]
     sign = getattr(ctx, "sign", None)
     if att == 3 and sign is not None:                   # gather-free: only the keys and the sign record are read
         if need_row or need_a:
@@ -202,16 +207,18 @@ def aux_backward(ctx, gout):
     if need_row or need_a:
         wi, perm, perm32 = _segments(rows, n_rows, chunk)
         other = (cols if perm is None else cols[perm]).to(torch.int32)
-        if att == 3:
+        if att == 4:
+            g_row, _ = _seg_att3(wi, other, perm32, gout, lo, hi, H, f_out, rowop, colop, None, n_rows, False)
+        elif att == 3:
             g_row, g_a = _seg_att3(wi, other, perm32, gout, lo, hi, H, f_out, rowop, colop, a, n_rows, need_a)
         else:
             g_row = _keybuf((n_rows, H * f_in), dev, wi)
             _seg_hx(0, wi, other, perm32, gout, lo, hi, H, f_in, x, g_row, False)
-    if (att == 3 and need_col) or (att == 2 and need_x):
+    if (att in (3, 4) and need_col) or (att == 2 and need_x):
         wi, perm, perm32 = _segments(cols, n_cols, chunk)
         other = (rows if perm is None else rows[perm]).to(torch.int32)
-        if att == 3:
-            g_col, _ = _seg_att3(wi, other, perm32, gout, lo, hi, H, f_out, colop, rowop, a, n_cols, False)
+        if att in (3, 4):
+            g_col, _ = _seg_att3(wi, other, perm32, gout, lo, hi, H, f_out, colop, rowop, a if att == 3 else None, n_cols, False)
         else:
             g_x = _keybuf(tuple(x.shape), dev, wi, x.stride(0) != f_in)
             _seg_hx(1, wi, other, perm32, gout, lo, hi, H, f_in, rowop, g_x, False)

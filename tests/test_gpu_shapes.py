@@ -23,6 +23,9 @@ CASES = [
     (24, 32, 40, 3, "AT"), (8, 64, 512, 3, "SAGE"), (4, 48, 1024, 3, "GCN"), (40, 20, 6, 1, "AT"), (20, 36, 12, 2, "SAGE"), (16, 257, 16, 2, "AT"), (32, 500, 8, 2, "GCN"),
     # wider than the register tile: aggregated in column slices (att 1 / 3 only)
     (4, 1433, 16, 3, "AT"), (8, 700, 32, 3, "SAGE"), (16, 300, 8, 1, "GCN"), (2, 1100, 24, 1, "AT"),
+    # att 2 wider than its register tile (F_in > 512, e.g. Cora's raw 1 433-wide bag of words with --origin_feat):
+    # scored through the per-head projections h = x W (kernel code 4), x aggregated in column slices
+    (4, 1433, 16, 2, "AT"), (8, 700, 32, 2, "SAGE"), (3, 520, 70, 2, "GCN"), (20, 600, 24, 2, "AT"),
 ]
 
 
@@ -41,7 +44,7 @@ def test_layer_shapes_forward_backward(dev, H, f_in, f_out, att, gnn, monkeypatc
     import edgedisentangle_ssl_amd as pkg
     from edgedisentangle_ssl_amd import ops
     from oracle import disgat_oracle as orc
-    monkeypatch.setattr(ops, "CHUNK", {1: 16, 2: 16, 3: 16})
+    monkeypatch.setattr(ops, "CHUNK", {1: 16, 2: 16, 3: 16, 4: 16})
     idx, n = small_graph()
     ci = ic.coalesced_index_set(idx, n)
     adj = torch.sparse_coo_tensor(idx, torch.ones(idx.shape[1]), (n, n)).to(dev)

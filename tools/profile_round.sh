@@ -1,0 +1,35 @@
+#!/bin/bash
+# rocprofv3 evidence for one round (run on the GPU box through gpurun):  tools/profile_round.sh <out-dir-under-gpurun_out>
+#   kernel-trace --stats of bench.py (C4 att 3 AT T_iter, + att 1, att 2, C3/SAGE), separate --pmc FETCH_SIZE and
+#   --pmc WRITE_SIZE passes of the headline, and SQ / TCC counters of the two GEMM kernels on their own shapes.
+# PMC passes never combine with sys/hip/hsa tracing (the pool refuses that); the profiled program is python3 itself.
+set -u
+ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
+OUT="$ROOT/gpurun_out/${1:-r02/prof}"
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+B="python3 $ROOT/bench.py --no-cpu-baseline --steps 3 --warmup 1"
+run() { # name, rocprof-args..., -- program...
+  local name=$1; shift
+  echo "[profile] $name"; date +%T
+  rocprofv3 "$@" > "$OUT/$name.log" 2>&1 || { echo "[profile] $name FAILED"; tail -5 "$OUT/$name.log"; return 1; }
+}
+run kt_c4_att3   --kernel-trace --stats --output-format csv -d "$OUT/kt_c4_att3"   -- $B &&
+run fetch_c4_att3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch_c4_att3" -- $B &&
+run write_c4_att3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write_c4_att3" -- $B &&
+run kt_c4_att1   --kernel-trace --stats --output-format csv -d "$OUT/kt_c4_att1"   -- $B --att 1 &&
+run kt_c4_att2   --kernel-trace --stats --output-format csv -d "$OUT/kt_c4_att2"   -- $B --att 2 &&
+run kt_c3_sage   --kernel-trace --stats --output-format csv -d "$OUT/kt_c3_sage"   -- $B --nodes 100000 --edges 2000000 --feat 128 --gnn_type SAGE &&
+run kt_c4_fwd    --kernel-trace --stats --output-format csv -d "$OUT/kt_c4_fwd"    -- $B --fwd-only &&
+for shape in "256 2048" "2048 256"; do
+  tag="gemm_$(echo $shape | tr ' ' 'x')"
+  run ${tag}_sq1 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_LDS --output-format csv -d "$OUT/${tag}_sq1" -- python3 $ROOT/tools/gemm_one.py $shape &&
+  run ${tag}_sq2 --pmc SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/${tag}_sq2" -- python3 $ROOT/tools/gemm_one.py $shape &&
+  run ${tag}_fetch --pmc FETCH_SIZE --output-format csv -d "$OUT/${tag}_fetch" -- python3 $ROOT/tools/gemm_one.py $shape &&
+  run ${tag}_write --pmc WRITE_SIZE --output-format csv -d "$OUT/${tag}_write" -- python3 $ROOT/tools/gemm_one.py $shape &&
+  run ${tag}_kt --kernel-trace --stats --output-format csv -d "$OUT/${tag}_kt" -- python3 $ROOT/tools/gemm_one.py $shape || break
+done
+echo "[profile] done"; date +%T
+# keep what travels back small: the per-dispatch trace CSVs can be tens of MB
+find "$OUT" -name "*kernel_trace.csv" -size +4M -delete
+du -sh "$OUT"

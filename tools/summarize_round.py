@@ -1,0 +1,110 @@
+#!/usr/bin/env python3
+"""Condense a tools/profile_round.sh output tree (gpurun_out/<round>/prof) into tracked summaries under profiles/<round>/.
+
+  python tools/summarize_round.py gpurun_out/r02/prof profiles/r02
+"""
+import csv
+import glob
+import os
+import shutil
+import sys
+
+NOTES = {
+    "kt_c4_att3": "bench.py default: C4 graph (1M nodes / 20M edges, F=256, H=8), att 3, AT, T_iter, 1 warm-up + 3 steps",
+    "kt_c4_att1": "bench.py --att 1 (same graph)",
+    "kt_c4_att2": "bench.py --att 2 (same graph)",
+    "kt_c3_sage": "bench.py --nodes 100000 --edges 2000000 --feat 128 --gnn_type SAGE (BASELINE configs[2])",
+    "kt_c4_fwd": "bench.py --fwd-only (T_fwd = one get_em per step)",
+}
+
+
+def one(path):
+    fs = glob.glob(os.path.join(path, "*", "*_kernel_stats.csv"))
+    return list(csv.DictReader(open(fs[0]))) if fs else []
+
+
+def counters(path):
+    """kernel -> counter -> list of per-dispatch values"""
+    out = {}
+    for f in glob.glob(os.path.join(path, "*", "*_counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"].split("(")[0]
+            out.setdefault(k, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    return out
+
+
+def main(src, dst):
+    os.makedirs(dst, exist_ok=True)
+    for tag, note in NOTES.items():
+        rows = one(os.path.join(src, tag))
+        if not rows:
+            continue
+        for f in glob.glob(os.path.join(src, tag, "*", "*_kernel_stats.csv")):
+            shutil.copy(f, os.path.join(dst, f"{tag}_kernel_stats.csv"))
+        with open(os.path.join(dst, f"{tag}_summary.md"), "w") as out:
+            P = lambda *a: print(*a, file=out)      # noqa: E731
+            P(f"# rocprofv3 --kernel-trace --stats: {tag}\n\n{note}\n")
+            tot = sum(int(r["TotalDurationNs"]) for r in rows)
+            P(f"Total kernel time {tot / 1e6:.1f} ms over all 4 steps (1 warm-up + 3 timed)\n")
+            P("| kernel | calls | total ms | avg ms | % |\n|---|---|---|---|---|")
+            for r in rows[:16]:
+                P(f"| `{r['Name'][:100]}` | {r['Calls']} | {int(r['TotalDurationNs']) / 1e6:.2f} | "
+                  f"{float(r['AverageNs']) / 1e6:.3f} | {float(r['Percentage']):.2f} |")
+            if tag == "kt_c4_att3":
+                P("\n## HBM traffic (separate `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes of the same command)\n")
+                P("rocprofv3 reports KiB.  gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE tallies the 128-B "
+                  "requests of 16-B-per-lane loads at 64 B, so read bytes = 2 x FETCH_SIZE x 1024; WRITE_SIZE is exact for "
+                  "16-B-per-lane stores.\n")
+                fe, wr = counters(os.path.join(src, "fetch_c4_att3")), counters(os.path.join(src, "write_c4_att3"))
+                P("| kernel | launches | FETCH_SIZE KiB/launch | WRITE_SIZE KiB/launch | corrected HBM bytes/launch (2F+W) |\n|---|---|---|---|---|")
+                for k in fe:
+                    if "disgat" not in k:
+                        continue
+                    f = fe[k].get("FETCH_SIZE", [0])
+                    w = wr.get(k, {}).get("WRITE_SIZE", [0])
+                    fa, wa = sum(f) / len(f), sum(w) / len(w)
+                    P(f"| `{k}` | {len(f)} | {fa:.4g} | {wa:.4g} | {(2 * fa + wa) * 1024 / 1e9:.2f} GB |")
+    # GEMM PMC
+    with open(os.path.join(dst, "gemm_f16x3_pmc.md"), "w") as out:
+        P = lambda *a: print(*a, file=out)      # noqa: E731
+        P("# f16x3 GEMM kernels: PMC counters (tools/gemm_one.py K N, M = 1,000,000, 4 launches, per-launch averages)\n")
+        P("Separate rocprofv3 passes per counter set (SQ set 1, SQ set 2, FETCH_SIZE, WRITE_SIZE) plus a kernel-trace pass "
+          "for the duration.  SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles; SQ_VALU_MFMA_BUSY_CYCLES "
+          "counts cycles (MI355X_MICROARCH.md).\n")
+        for shape, what in (("256x2048", "P / Q operands [1e6,256] x [256,2048]: gemm_f16x3_as_kernel<0> (A-stationary)"),
+                            ("2048x256", "FuseLayer [1e6,2048] x [2048,256]: gemm_f16x3_kernel (tiled)")):
+            P(f"\n## {what}\n")
+            kt = [r for r in one(os.path.join(src, f"gemm_{shape}_kt")) if "gemm" in r["Name"]]
+            dur = None
+            for r in kt:
+                dur = float(r["AverageNs"]) / 1e6
+                P(f"`{r['Name'][:80]}`: {r['Calls']} calls, avg **{dur:.3f} ms** "
+                  f"({2.0 * 1e6 * 256 * 2048 / (dur * 1e-3) / 1e12:.0f} TFLOP/s fp32-equivalent, x3 fp16 MFMA products inside)\n")
+            P("| counter | per launch |\n|---|---|")
+            vals = {}
+            for sub in ("sq1", "sq2", "fetch", "write"):
+                for k, cs in counters(os.path.join(src, f"gemm_{shape}_{sub}")).items():
+                    if "gemm_f16x3" not in k:
+                        continue
+                    for c, v in cs.items():
+                        vals[c] = sum(v) / len(v)
+            for c, v in vals.items():
+                P(f"| {c} | {v:.4g} |")
+            if "SQ_VALU_MFMA_BUSY_CYCLES" in vals and dur:
+                # 1024 SIMDs (256 CUs x 4); the counter sums busy cycles over all SIMDs
+                for ghz in (2.4, 2.0):
+                    P(f"\nMFMA pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x {ghz} GHz x {dur:.3f} ms) = "
+                      f"**{vals['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * ghz * 1e9 * dur * 1e-3) * 100:.0f} %**")
+            if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+                P(f"\nHBM bytes per launch (2 x FETCH + WRITE, KiB -> bytes): read {2 * vals['FETCH_SIZE'] * 1024 / 1e9:.2f} GB, "
+                  f"write {vals['WRITE_SIZE'] * 1024 / 1e9:.2f} GB")
+            if all(k in vals for k in ("SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY")):
+                w = vals["SQ_WAVE_CYCLES"]
+                P(f"\nWave time: {vals['SQ_ACTIVE_INST_ANY'] / w * 100:.0f} % issuing, {vals['SQ_WAIT_INST_ANY'] / w * 100:.0f} % "
+                  f"issue-stalled, {vals['SQ_WAIT_ANY'] / w * 100:.0f} % parked at s_waitcnt / barrier")
+    print(open(os.path.join(dst, "gemm_f16x3_pmc.md")).read())
+    print(open(os.path.join(dst, "kt_c4_att3_summary.md")).read())
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
