@@ -50,7 +50,9 @@ def parse():
     ap.add_argument("--att", type=int, default=3)
     ap.add_argument("--gnn_type", default="AT")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-nodes", type=int, default=2048)
+    ap.add_argument("--cpu-nodes", type=int, default=16384)
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary measurements (T_fwd, skip-unused T_iter, exact-operand GEMM T_iter, training step)")
     ap.add_argument("--fwd-only", action="store_true", help="time one get_em (T_fwd) instead of T_iter")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="N>1: weak = 1M rows per rank of an N-times larger graph; strong = the same graph cut in N")
@@ -74,8 +76,10 @@ def ops_gemm_mode():
 
 
 def gemm_check(x, enc, dev):
-    """Max error of the path's GEMM scheme against float64 on the workload's own operands (first 8192 rows of x times
-    the first head's score weight), next to hipBLASLt's fp32 GEMM on the same data; relative to the output maximum."""
+    """Error of the path's GEMM scheme against float64 on the workload's own operands (first 8192 rows of x times the
+    layer-1 score weights), next to hipBLASLt's fp32 GEMM on the same data.  Two views: relative to the output
+    maximum, and per element - |err_ij| against that element's own rounding scale sum_k |a_ik w_kj| (what an fp32 dot
+    product of those terms can be held to; a plain fp32 accumulation sits at ~1e-7..1e-6 of it)."""
     from edgedisentangle_ssl_amd import ops_gemm
     with torch.no_grad():
         a = x[:8192].contiguous()
@@ -83,10 +87,15 @@ def gemm_check(x, enc, dev):
         if w.shape[1] % 128 or a.shape[1] % 32:
             return None
         ref = a.double() @ w.double()
+        mag = a.double().abs() @ w.double().abs()
         scale = float(ref.abs().max())
-        ours = float((ops_gemm.linear(a, w).double() - ref).abs().max()) / scale
-        blas = float(((a @ w).double() - ref).abs().max()) / scale
-    return {"ours_vs_fp64": ours, "hipblaslt_fp32_vs_fp64": blas, "sample": f"{a.shape[0]}x{a.shape[1]} @ {tuple(w.shape)}"}
+        e_ours = (ops_gemm.linear(a, w).double() - ref).abs()
+        e_blas = ((a @ w).double() - ref).abs()
+        out = {"ours_vs_fp64": float(e_ours.max()) / scale, "hipblaslt_fp32_vs_fp64": float(e_blas.max()) / scale,
+               "per_element_ours_max": float((e_ours / mag).max()), "per_element_hipblaslt_max": float((e_blas / mag).max()),
+               "per_element_ours_p999": float(torch.quantile((e_ours / mag).flatten()[:4_000_000], 0.999)),
+               "sample": f"{a.shape[0]}x{a.shape[1]} @ {tuple(w.shape)}; per_element = |err| / sum_k |a_ik w_kj|"}
+    return out
 
 
 def sharded_graph(o, rank, world, dev):
@@ -215,48 +224,52 @@ def usable_cores():
     return max(1, min(n, int(os.environ.get("DISGAT_CPU_THREADS", "16"))))
 
 
-def cpu_baseline(o):
+def cpu_baseline(o, feat=None, gnn=None, one_run=False):
     """The oracle (CPU restatement of the reference's op sequence: kind "port") timed on this box's
     host cores on a bounded sample of the same workload: same generator, feature width, heads and
-    attention type, fewer nodes (about 10-30 s of CPU work)."""
+    attention type, fewer nodes (--cpu-nodes; the per-edge cost of the CPU path is flat in N)."""
     from oracle import disgat_oracle as orc
-    from edgedisentangle_ssl_amd import DISGAT, MLP, FuseLayer, sampling, synth
+    from edgedisentangle_ssl_amd import DISGAT, MLP, FuseLayer, synth
     torch.set_num_threads(usable_cores())
+    feat = o.feat if feat is None else feat
+    gnn = o.gnn_type if gnn is None else gnn
     n = o.cpu_nodes
     e = n * (o.edges // o.nodes)
     cpu = torch.device("cpu")
     graph = synth.powerlaw_graph(n, e, cpu)
     labels = synth.node_labels(n, cpu)
     (si, sl), (hi, hl), (ti, tl) = synth.ssl_lists(graph, labels)
-    x = synth.features(n, o.feat, cpu)
+    x = synth.features(n, feat, cpu)
     a = make_args(o)
+    a.gnn_type, a.nhid, a.size = gnn, feat, feat
     torch.manual_seed(0)
-    enc = DISGAT(a, nfeat=o.feat, nhid=o.feat, nclass=o.feat, nheads=o.heads, dropout=0.0)
+    enc = DISGAT(a, nfeat=feat, nhid=feat, nclass=feat, nheads=o.heads, dropout=0.0)
     sd = {k: v.detach() for k, v in enc.state_dict().items()}
     fus = []
     for _ in range(3):
-        pair = [FuseLayer(a, o.heads, nfeat=o.feat), FuseLayer(a, o.heads, nfeat=o.feat)]
+        pair = [FuseLayer(a, o.heads, nfeat=feat), FuseLayer(a, o.heads, nfeat=feat)]
         fus.append([(lambda hs, r, p={k: v.detach() for k, v in f.state_dict().items()}: orc.fuse_layer(p, hs, r)) for f in pair])
-    c1 = {k: v.detach() for k, v in MLP(o.feat * 2, o.feat, o.heads).state_dict().items()}
-    c2 = {k: v.detach() for k, v in MLP(o.feat * 2, o.feat, o.heads).state_dict().items()}
+    c1 = {k: v.detach() for k, v in MLP(feat * 2, feat, o.heads).state_dict().items()}
+    c2 = {k: v.detach() for k, v in MLP(feat * 2, feat, o.heads).state_dict().items()}
     ei = graph.indices()
 
     def step():
         with torch.no_grad():
-            r = orc.disgat_pass(sd, x, ei, fus[0], o.heads, o.att, o.gnn_type, [si])
+            r = orc.disgat_pass(sd, x, ei, fus[0], o.heads, o.att, gnn, [si])
             l1 = orc.sup_edge_loss(r["aux"], sl)
-            r = orc.disgat_pass(sd, x, ei, fus[1], o.heads, o.att, o.gnn_type, [hi, ti])
+            r = orc.disgat_pass(sd, x, ei, fus[1], o.heads, o.att, gnn, [hi, ti])
             l2 = orc.dis_edge_loss(r["aux"], hl, tl)
-            r = orc.disgat_pass(sd, x, ei, fus[2], o.heads, o.att, o.gnn_type)
+            r = orc.disgat_pass(sd, x, ei, fus[2], o.heads, o.att, gnn)
             l3 = orc.dif_head_loss(r["edge_em"], c1, c2)
         return float(l1 + l2 + l3)
 
-    print(f"[bench] cpu_baseline: oracle on N={n} nnz={graph.nnz}, {torch.get_num_threads()} threads ...", file=sys.stderr, flush=True)
+    print(f"[bench] cpu_baseline: oracle on N={n} nnz={graph.nnz} F={feat} {gnn}, {torch.get_num_threads()} threads ...",
+          file=sys.stderr, flush=True)
     t0 = time.time()
     step()
     t1 = time.time() - t0
-    print(f"[bench] cpu_baseline warm-up step {t1:.1f}s", file=sys.stderr, flush=True)
-    if t1 > 40:            # far slower host than planned for: keep the bench bounded, report the one run
+    print(f"[bench] cpu_baseline first step {t1:.1f}s", file=sys.stderr, flush=True)
+    if one_run or t1 > 25:     # keep the whole bench within a few minutes: report the one (cold) run
         reps, dt = 0, t1
     else:
         reps = 1 if t1 > 12 else 2
@@ -265,8 +278,79 @@ def cpu_baseline(o):
             step()
         dt = (time.time() - t0) / reps
     return {"value": graph.nnz / dt, "unit": "edges/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"same generator/config, N={n} nnz={graph.nnz} F={o.feat} H={o.heads} att={o.att} "
-                      f"gnn={o.gnn_type}, T_iter {dt:.2f}s, " + (f"mean of {reps} run(s) after 1 warm-up" if reps else "single cold run")}
+            "sample": f"same generator/config, N={n} nnz={graph.nnz} F={feat} H={o.heads} att={o.att} "
+                      f"gnn={gnn}, T_iter {dt:.2f}s, " + (f"mean of {reps} run(s) after 1 warm-up" if reps else "single cold run")}
+
+
+def secondary_measurements(o, enc, trainers, graph, x, lists):
+    """Numbers next to the headline, from the same process and inputs (rank 0, N = 1): T_fwd (one get_em, SURVEY 8d
+    "secondary"), T_iter without the layer-2 work predict_adjs_sparse discards, T_iter on the exact-operand GEMM scheme,
+    and a full training iteration (3 SSL losses: forward + backward + Adam, attention dropout 0.1)."""
+    import copy
+    from edgedisentangle_ssl_amd import layers as L
+
+    def timed(fn, steps, warm=1):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps * 1e3
+
+    out = {}
+    of = copy.copy(o)
+    of.fwd_only = True
+    out["T_fwd_ms"] = round(timed(lambda: one_step(of, enc, trainers, graph, x, lists), 5), 3)
+    out["T_fwd_edges_per_s"] = round(graph.nnz / (out["T_fwd_ms"] * 1e-3))
+    prev = enc.skip_unused
+    enc.skip_unused = True
+    out["T_iter_skip_unused_ms"] = round(timed(lambda: one_step(o, enc, trainers, graph, x, lists), 3), 3)
+    enc.skip_unused = prev
+    old_mode = os.environ.get("DISGAT_GEMM")
+    os.environ["DISGAT_GEMM"] = "split6"
+    L.clear_weight_cache(enc)
+    try:
+        out["T_iter_split6_ms"] = round(timed(lambda: one_step(o, enc, trainers, graph, x, lists), 2), 3)
+    finally:
+        if old_mode is None:
+            os.environ.pop("DISGAT_GEMM", None)
+        else:
+            os.environ["DISGAT_GEMM"] = old_mode
+        L.clear_weight_cache(enc)
+    # training iteration: dropout 0.1 on, autograd on, Adam steps.  It updates the weights, so it runs LAST (after the
+    # headline, the GEMM check and every other secondary number)
+    sup, dis, dif = trainers
+    (si, sl), (hi, hl), (ti, tl) = lists
+    data = (x, graph)
+    for m in enc.modules():
+        if hasattr(m, "dropout"):
+            m.dropout = 0.1
+
+    def train():
+        for tr, fn in ((sup, lambda: sup.loss(data, sl, [si])), (dis, lambda: dis.loss(data, [hl, tl], [hi, ti])),
+                       (dif, lambda: dif.loss(data))):
+            tr._begin_step()
+            tr._finish_step(fn(), graph)
+    try:
+        torch.cuda.reset_peak_memory_stats()
+        out["train_step_ms"] = round(timed(train, 2), 3)
+        out["train_step_peak_GiB"] = round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)
+        out["train_step_def"] = "SupEdge + DisEdge + DifHead: forward + backward + multi-tensor Adam, attention dropout 0.1"
+    except torch.OutOfMemoryError as exc:          # report, never fail the headline over a secondary number
+        out["train_step_ms"] = None
+        out["train_step_error"] = str(exc)[:200]
+    finally:
+        for m in enc.modules():
+            if hasattr(m, "dropout"):
+                m.dropout = 0.0
+        for tr in trainers:
+            for m in tr.models:
+                m.eval()
+                for p_ in m.parameters():
+                    p_.grad = None
+    return out
 
 
 def launch_ranks(o):
@@ -410,8 +494,14 @@ def main():
     cpu = None
     if not o.no_cpu_baseline and world == 1:          # rank 0, N=1 only (bench contract)
         cpu = cpu_baseline(o)
+        if (o.feat, o.gnn_type) != (128, "SAGE"):      # BASELINE configs[2]'s shape (F = 128, SAGE) beside it, one run
+            c3 = cpu_baseline(o, feat=128, gnn="SAGE", one_run=True)
+            cpu["configs2_F128_SAGE"] = {k: c3[k] for k in ("value", "unit", "sample")}
     ms = dt / o.steps * 1e3
     gemm_chk = gemm_check(x, enc, dev) if rank == 0 else None
+    secondary = None
+    if world == 1 and not o.no_secondary and not o.fwd_only:
+        secondary = secondary_measurements(o, enc, trainers, graph, x, lists)
     what = "T_fwd(get_em)" if o.fwd_only else "T_iter(SupEdge+DisEdge+DifHead fwd+loss)"
     if o.skip_unused and not o.fwd_only:
         what += " with the discarded layer-2 aggregation of predict_adjs_sparse skipped (secondary definition)"
@@ -437,7 +527,7 @@ def main():
                    "ranks_seen": world, "backend": None if world == 1 else dist.get_backend(),
                    "gemm_scheme": ops_gemm_mode(), "gemm_check": gemm_chk,
                    "csr_build_ms": None if getattr(graph, "prep_ms", None) is None else round(graph.prep_ms, 1)},
-        "roofline": roof, "cpu_baseline": cpu,
+        "roofline": roof, "cpu_baseline": cpu, "secondary": secondary,
     }
     if rehearsal and world > 1:
         out["config"]["rehearsal"] = "all ranks share cuda:0 over gloo: functional check of the N-rank path, NOT a scaling number"

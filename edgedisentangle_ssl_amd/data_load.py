@@ -44,9 +44,36 @@ def normalize_features(f):
     return (f * inv[:, None]).astype(np.float32)
 
 
-def load_data(args, path="data/dblp/", dataset="dblp", edge_type=3):
+def processed_csr(a):
+    """Host CSR (indptr int64, indices int32) of the index set of (A + A^T + I): all the DISGAT path reads of the
+    processed adjacency (layers.py:344 takes adj.coalesce().indices(); the row-normalised values are ignored)."""
+    n = a.shape[0]
+    b = ((a + a.T + sp.eye(n, format="csr")) != 0).tocsr()
+    b.sort_indices()
+    return b.indptr.astype(np.int64), b.indices.astype(np.int32)
+
+
+def partition_graph(indptr, indices, rank, world, device, group=None):
+    """This rank's nnz-balanced row range of a host CSR as a parallel.DistGraph, built directly from the slice: the
+    replicated structure never reaches the device ("partitioned on load for multi-GPU")."""
+    from .parallel import DistGraph, balanced_row_ranges
+    n = indptr.shape[0] - 1
+    b = balanced_row_ranges(torch.from_numpy(indptr), world)
+    lo, hi = int(b[rank]), int(b[rank + 1])
+    e0, e1 = int(indptr[lo]), int(indptr[hi])
+    rp = torch.from_numpy((indptr[lo:hi + 1] - e0).astype(np.int32)).to(device)
+    col = torch.from_numpy(np.ascontiguousarray(indices[e0:e1])).to(device)
+    row = torch.repeat_interleave(torch.arange(hi - lo, device=device), (rp[1:] - rp[:-1]).long())
+    return DistGraph(hi - lo, rp.contiguous(), col.contiguous(), row.contiguous(), n, lo, (b[1:] - b[:-1]).tolist(), group)
+
+
+def load_data(args, path="data/dblp/", dataset="dblp", edge_type=3, rank=None, world=None, device="cpu", group=None):
     """Same signature and return convention as the reference: (adjs, features, labels); adjs is a list
-    of sparse tensors when args.hetero else a single one."""
+    of sparse tensors when args.hetero else a single one.
+
+    rank / world (not in the reference): partition on load for a multi-GPU run - adjs become this rank's
+    parallel.DistGraph (local rows, global columns, nnz-balanced), features the rank's own rows (both on `device`),
+    labels stay global (the trainers index them with global node ids)."""
     labels = torch.from_numpy(np.load(os.path.join(path, "label.npy")).astype(np.int64))
     if getattr(args, "origin_feat", False):
         feats = np.load(os.path.join(path, "feature.npy")).astype(np.float32)
@@ -64,6 +91,11 @@ def load_data(args, path="data/dblp/", dataset="dblp", edge_type=3):
         use = [edges[args.used_edge - 1]]
     if not args.sparse:
         raise NotImplementedError("dense adjacency (no --sparse) is outside the HIP path")
+    if world is not None and world > 1:
+        adjs = [partition_graph(*processed_csr(a), rank, world, device, group) for a in use]
+        lo = adjs[0].row_start
+        feats = torch.from_numpy(np.ascontiguousarray(feats[lo: lo + adjs[0].n])).to(device)
+        return (adjs, feats, labels) if args.hetero else (adjs[0], feats, labels)
     adjs = [process_adj(a) for a in use]
     feats = torch.from_numpy(feats)
     return (adjs, feats, labels) if args.hetero else (adjs[0], feats, labels)

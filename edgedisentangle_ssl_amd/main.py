@@ -71,20 +71,37 @@ def run(argv=None, log=print):
     if unsupported:
         raise SystemExit("SSL tasks {} are outside the DISGAT hot path (SURVEY 2 row 19)".format(unsupported))
 
+    # one process per GPU (torch.distributed.run sets RANK / WORLD_SIZE / LOCAL_RANK): the graph is partitioned by
+    # row ranges on load, every rank keeps its own rows of the features, labels stay global
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) if world > 1 else torch.cuda.current_device())
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(dev)
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("nccl", device_id=dev)
     if args.fixture:
         adj, features, labels = data_load.load_fixture(args.fixture)
         if features is None:
             features = surrogate_features(adj.shape[0], 64, seed=51)
-        adjs = [adj]
+        adjs = [adj.to(dev)]
+        features = features.to(dev)
+        if world > 1:
+            from .graph import CSRGraph
+            from .parallel import DistGraph
+            adjs = [DistGraph.shard(CSRGraph.from_adj(adjs[0]), rank, world)]
+            features = features[adjs[0].row_start: adjs[0].row_start + adjs[0].n].contiguous()
     else:
         args.edge_num = 1
         adjs, features, labels = data_load.load_data(args, path="{}/{}/".format(args.data_root, args.dataset),
-                                                     dataset=args.dataset, edge_type=args.edge_num)
+                                                     dataset=args.dataset, edge_type=args.edge_num,
+                                                     rank=rank, world=world, device=dev)
+        adjs = [a.to(dev) if torch.is_tensor(a) else a for a in adjs]
+        features = features.to(dev)
     args.size = features.shape[1]
     args.nclass = labels.max().item() + 1
-    dev = torch.device("cuda")
-    features, labels = features.to(dev), labels.to(dev)
-    adjs = [a.to(dev) for a in adjs]
+    labels = labels.to(dev)
 
     encoder = models.DISGAT(args, nfeat=args.size, nhid=args.nhid, nclass=args.nhid, nheads=args.nhead,
                             dropout=args.dropout).to(dev)                  # main.py:142-147
