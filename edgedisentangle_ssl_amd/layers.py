@@ -256,7 +256,8 @@ def disga_heads(layers, x, adj, aux_indices=None, head_ranges=None, aux_only=Fal
     # slice: correct, not cheap).  att 2's score is a dot product over all of x and cannot be sliced.
     tile = min(512, 256 * max(1, 16 // Hk))
     assert not (att == 2 and f_in_p > tile), "att 2 wider than its register tile is routed to the projected form above"
-    x_all = parallel.all_gather_rows(x, graph)       # sharded: one exchange per layer
+    # sharded: one exchange per layer - all rows, or only the referenced ones for edge-only passes
+    x_all, graph = parallel.exchange(x, graph, edge_only=aux_indices is None)
     xg = x_all if (f_in_p == f_in and x_all.is_contiguous()) else F.pad(x_all, (0, f_in_p - f_in)).contiguous()
 
     # Scale inputs of the f16x3 GEMMs.  max |x| is measured once (1 pass over the layer input); the two 8x larger

@@ -111,6 +111,93 @@ def all_gather_rows(x_local, graph):
     return _AllGatherRows.apply(x_local, graph.counts, graph.group)
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# Halo-only exchange (north_star: "halo features"): a rank fetches just the rows its edges reference instead of all
+# N_global rows.  Worth it when the referenced set is a small part of the graph (graphs with locality / many ranks);
+# on BASELINE.json's random-column generator a rank references 71-92 % of all nodes, and a pass that scores auxiliary
+# pairs (uniform random columns) needs every row anyway, so `exchange()` picks per call:
+#   DISGAT_EXCHANGE=auto (default): halo for edge-only passes when the referenced set is < 60 % of the graph,
+#   =halo: halo for every edge-only pass, =allgather: never.
+def _a2a(out, inp, out_splits, in_splits, group):
+    """all_to_all_single; gloo moves CUDA tensors through the host (the rehearsal / test configuration)."""
+    if inp.is_cuda and dist.get_backend(group) == "gloo":
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(o, inp.cpu(), out_splits, in_splits, group=group)
+        out.copy_(o)
+    else:
+        dist.all_to_all_single(out, inp.contiguous(), out_splits, in_splits, group=group)
+    return out
+
+
+class HaloPlan:
+    """Built once per DistGraph: which global rows this rank's edges reference (`ref`, sorted = ordered by owner),
+    which of its own rows every peer wants (`send_idx`, `send_counts`), how many rows arrive from every peer
+    (`recv_counts`), and the graph re-indexed to the compact table (`graph_c`: column ids = positions in `ref`)."""
+
+    def __init__(self, graph):
+        dev = graph.col.device
+        world, group = graph.world, graph.group
+        ref = torch.unique(graph.col.to(torch.int64))
+        bounds = torch.cat([torch.zeros(1, dtype=torch.int64), torch.tensor(graph.counts, dtype=torch.int64).cumsum(0)]).to(dev)
+        owner = torch.searchsorted(bounds, ref, right=True) - 1
+        recv_counts = torch.bincount(owner, minlength=world)
+        send_counts = torch.empty_like(recv_counts)
+        _a2a(send_counts, recv_counts, [1] * world, [1] * world, group)
+        self.recv_counts = recv_counts.tolist()
+        self.send_counts = send_counts.tolist()
+        want = torch.empty(sum(self.send_counts), dtype=torch.int64, device=dev)      # ids the peers want from me
+        _a2a(want, ref, self.send_counts, self.recv_counts, group)
+        self.send_idx = (want - graph.row_start).contiguous()
+        assert self.send_idx.numel() == 0 or (int(self.send_idx.min()) >= 0 and int(self.send_idx.max()) < graph.n)
+        self.ref = ref
+        self.n_ref = int(ref.numel())
+        self.group = group
+        col_c = torch.searchsorted(ref, graph.col.to(torch.int64)).to(torch.int32)
+        gc = CSRGraph(graph.n, graph.rowptr, col_c.contiguous(), graph.row)
+        gc.n_cols = self.n_ref
+        gc.row_start = graph.row_start
+        self.graph_c = gc
+
+
+class _HaloRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, plan):
+        ctx.plan = plan
+        out = x.new_empty((plan.n_ref,) + tuple(x.shape[1:]))
+        _a2a(out, x[plan.send_idx], plan.recv_counts, plan.send_counts, plan.group)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        """Adjoint: every referenced row's gradient travels back to its owner, which sums what it receives."""
+        plan = ctx.plan
+        back = g.new_empty((plan.send_idx.numel(),) + tuple(g.shape[1:]))
+        _a2a(back, g.contiguous(), plan.send_counts, plan.recv_counts, plan.group)
+        gx = g.new_zeros((plan.graph_c.n,) + tuple(g.shape[1:]))
+        gx.index_add_(0, plan.send_idx, back)
+        return gx, None
+
+
+def exchange(x_local, graph, edge_only):
+    """The per-layer exchange.  Returns (x_cols, graph_eff): the operand table column ids of `graph_eff`
+    index.  Unsharded: (x_local, graph).  Sharded: the full all-gather (graph unchanged), or - for passes that score
+    no auxiliary pairs - the halo exchange with the compact re-indexed graph."""
+    if not isinstance(graph, DistGraph) or graph.world == 1:
+        return x_local, graph
+    import os
+    mode = os.environ.get("DISGAT_EXCHANGE", "auto")
+    if edge_only and mode != "allgather":
+        plan = graph.__dict__.get("_halo")
+        if plan is None:
+            plan = graph._halo = HaloPlan(graph)
+            frac = torch.tensor([plan.n_ref / max(1, graph.n_global)], dtype=torch.float64, device=x_local.device)
+            dist.all_reduce(frac, op=dist.ReduceOp.MAX, group=graph.group)            # one decision for all ranks
+            plan.worth_it = float(frac) < 0.6
+        if mode == "halo" or plan.worth_it:
+            return _HaloRows.apply(x_local, plan), plan.graph_c
+    return _AllGatherRows.apply(x_local, graph.counts, graph.group), graph
+
+
 def all_reduce_grads(modules, graph):
     """Data-parallel gradient reduction: every rank holds the replicated parameters and the gradient
     contribution of its own rows / pairs; the global gradient is their sum.  The bucket covers EVERY parameter

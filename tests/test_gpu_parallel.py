@@ -71,6 +71,15 @@ def _worker(rank, world, port, q, golden_dir):
             for l in range(2):
                 err = (em[l] - ref_em[l][lo:hi]).abs().max().item()
                 assert err <= 1e-5 * max(1.0, ref_em[l].abs().max().item()), (gnn, att, l, err)
+            # the same forward over the halo-only exchange (only referenced rows travel, compact column ids)
+            os.environ["DISGAT_EXCHANGE"] = "halo"
+            with torch.no_grad():
+                em_h = enc.get_em(xl, dg, fus)
+            os.environ.pop("DISGAT_EXCHANGE")
+            assert getattr(dg, "_halo", None) is not None and dg._halo.n_ref <= n
+            for l in range(2):
+                err = (em_h[l] - ref_em[l][lo:hi]).abs().max().item()
+                assert err <= 1e-5 * max(1.0, ref_em[l].abs().max().item()), ("halo", gnn, att, l, err)
             for nm, got, want in (("sup", l_sup, ref_sup), ("dis", l_dis, ref_dis), ("dif", l_dif, ref_dif)):
                 assert abs(got.item() - want.item()) <= 2e-6 * max(1.0, abs(want.item())), (gnn, att, nm, got.item(), want.item())
 

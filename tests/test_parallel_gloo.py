@@ -68,6 +68,33 @@ def _worker(rank, world, port, q):
         assert torch.allclose(h_loc[lo:lo + dg.n], h_all[lo:lo + dg.n], atol=1e-6)
         assert torch.allclose(e_loc, e_all[e0:e0 + dg.nnz], atol=1e-6)
 
+        # halo-only exchange: just the referenced rows travel; the compact graph indexes the received table
+        os.environ["DISGAT_EXCHANGE"] = "halo"
+        xh = x[lo:lo + dg.n].clone().requires_grad_(True)
+        x_ref, gc = parallel.exchange(xh, dg, edge_only=True)
+        plan = dg._halo
+        assert torch.equal(plan.ref, torch.unique(dg.col.long())) and x_ref.shape[0] == plan.n_ref == gc.n_cols
+        assert torch.equal(x_ref.detach(), x[plan.ref]) and torch.equal(plan.ref[gc.col.long()], dg.col.long())
+        assert gc.n == dg.n and torch.equal(gc.rowptr, dg.rowptr)
+        # column-side score operand taken from the compact table == taken from the global one (att 3: Q = x W_bot)
+        q_ref, q_all = x_ref.detach() @ p["W"][16:], x @ p["W"][16:]
+        assert torch.equal(q_ref[gc.col.long()], q_all[dg.col.long()])
+        wgt = torch.arange(n, dtype=torch.float32).unsqueeze(1) * (rank + 1)
+        (x_ref * wgt[plan.ref]).sum().backward()                    # adjoint: owners sum what every rank sends back
+        refd = torch.zeros(n)
+        refd[plan.ref] = 1.0
+        cnt = refd * (rank + 1)
+        dist.all_reduce(cnt)                                        # sum over ranks of (rank+1) * [row referenced there]
+        want_h = (torch.arange(n, dtype=torch.float32) * cnt).unsqueeze(1).expand(n, 16)[lo:lo + dg.n]
+        assert torch.allclose(xh.grad, want_h)
+        # an exchange for a pass with auxiliary pairs is always the full all-gather; "auto" decides by the referenced share
+        xa2, g2 = parallel.exchange(xl.detach(), dg, edge_only=False)
+        assert g2 is dg and torch.equal(xa2, x)
+        os.environ["DISGAT_EXCHANGE"] = "allgather"
+        xa3, g3 = parallel.exchange(xl.detach(), dg, edge_only=True)
+        assert g3 is dg and torch.equal(xa3, x)
+        os.environ.pop("DISGAT_EXCHANGE")
+
         # global pair loss from per-rank partial sums (what pretrainer.pair_mse_loss reduces)
         pairs, lab = ic.sample_pairs(31, n, np.sort((g.row * n + g.col.long()).numpy()), "sup")
         mine = (pairs[0] >= lo) & (pairs[0] < lo + dg.n)
