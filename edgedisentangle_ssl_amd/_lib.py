@@ -60,6 +60,7 @@ def _build_locked(verbose):
     def one(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
         cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
+               *os.environ.get("DISGAT_HIPCC_FLAGS", "").split(),          # e.g. -DNAME for same-box A/B builds (tools/)
                "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:

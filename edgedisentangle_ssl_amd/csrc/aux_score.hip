@@ -180,6 +180,9 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void aux_att2_kernel(const AuxArgs
     for (int t = 0; t < KEEP; ++t) keep[t] = (mine && slot == t) ? e : keep[t];
   };
 
+  // 2-deep gather pipeline.  Measured on the same box: a 4-deep one (as in the att-1 / att-2 edge pass) 5.09 vs 5.14 TB/s,
+  // a v_pk_fma_f32 form of the dot products 4.77 vs 5.09 - the kernel is bound by the H dot products + butterfly, not
+  // by latency
   load_x(xA, __builtin_amdgcn_readlane(cv, 0));
   int i = 0;
   for (; i + 1 < cnt; i += 2) {

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void edge_fwd_kernel(const EdgeFwd
       float part[H];
 #pragma unroll
       for (int hh = 0; hh < H; ++hh) {
-        float acc = 0.f;
+        float acc = 0.f;     // scalar FMAs: a v_pk_fma_f32 form of these dot products measured 3 % slower (4.15 vs 4.28 TB/s)
 #pragma unroll
         for (int t = 0; t < XN; ++t) acc = dot4(p_r[hh * XN + t], b.xv[t], acc);
         part[hh] = acc;
@@ -181,24 +181,59 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void edge_fwd_kernel(const EdgeFwd
     }
   };
 
-  // ---- edge loop: 64 column indices per coalesced load, 2-deep operand pipeline
-  Buf bufA, bufB;
-  for (int kbase = kb; kbase < ke; kbase += 64) {
-    const int cnt = min(64, ke - kbase);
-    const int cv = (lane < cnt) ? A.col[kbase + lane] : 0;
-    load_edge(bufA, __builtin_amdgcn_readlane(cv, 0));
-    int i = 0;
-    for (; i + 1 < cnt; i += 2) {
-      load_edge(bufB, __builtin_amdgcn_readlane(cv, i + 1));
-      compute(bufA, (int64_t)kbase + i, i);
-      if (i + 2 < cnt) load_edge(bufA, __builtin_amdgcn_readlane(cv, i + 2));
-      compute(bufB, (int64_t)kbase + i + 1, i + 1);
-    }
-    if (i < cnt) compute(bufA, (int64_t)kbase + i, i);
+  // ---- edge loop: 64 column indices per coalesced load; gathered operands run ahead of the arithmetic in a register
+  // pipeline - 2 deep for att 3 / 4 (8-9 KB per edge: two edges per wave already keep ~18 KB in flight), 4 deep for
+  // att 1 / 2, whose edges bring only the 1 KB x row (a 2-deep pipeline left the wave waiting on HBM latency: 4.0-4.2
+  // TB/s against 5.8 for att 3; a buffer is 4-5 registers there)
+  auto flush = [&](int kbase, int cnt) {
     float* ep = A.edge_e + (int64_t)myh * A.E + kbase + ge;
 #pragma unroll
     for (int t = 0; t < H; ++t)
       if (t * GE + ge < cnt) ep[t * GE] = keep[t];
+  };
+  if constexpr (PQ) {
+    Buf bufA, bufB;
+    for (int kbase = kb; kbase < ke; kbase += 64) {
+      const int cnt = min(64, ke - kbase);
+      const int cv = (lane < cnt) ? A.col[kbase + lane] : 0;
+      load_edge(bufA, __builtin_amdgcn_readlane(cv, 0));
+      int i = 0;
+      for (; i + 1 < cnt; i += 2) {
+        load_edge(bufB, __builtin_amdgcn_readlane(cv, i + 1));
+        compute(bufA, (int64_t)kbase + i, i);
+        if (i + 2 < cnt) load_edge(bufA, __builtin_amdgcn_readlane(cv, i + 2));
+        compute(bufB, (int64_t)kbase + i + 1, i + 1);
+      }
+      if (i < cnt) compute(bufA, (int64_t)kbase + i, i);
+      flush(kbase, cnt);
+    }
+  } else {
+    Buf b0, b1, b2, b3;
+    for (int kbase = kb; kbase < ke; kbase += 64) {
+      const int cnt = min(64, ke - kbase);
+      const int cv = (lane < cnt) ? A.col[kbase + lane] : 0;
+      // lanes >= cnt hold column 0 (valid memory): loads past the batch end are harmless and never consumed
+      load_edge(b0, __builtin_amdgcn_readlane(cv, 0));
+      load_edge(b1, __builtin_amdgcn_readlane(cv, 1));
+      load_edge(b2, __builtin_amdgcn_readlane(cv, 2));
+      for (int i = 0; i < cnt; i += 4) {
+        load_edge(b3, __builtin_amdgcn_readlane(cv, (i + 3) & 63));
+        compute(b0, (int64_t)kbase + i, i);
+        if (i + 1 < cnt) {
+          load_edge(b0, __builtin_amdgcn_readlane(cv, (i + 4) & 63));
+          compute(b1, (int64_t)kbase + i + 1, i + 1);
+        }
+        if (i + 2 < cnt) {
+          load_edge(b1, __builtin_amdgcn_readlane(cv, (i + 5) & 63));
+          compute(b2, (int64_t)kbase + i + 2, i + 2);
+        }
+        if (i + 3 < cnt) {
+          load_edge(b2, __builtin_amdgcn_readlane(cv, (i + 6) & 63));
+          compute(b3, (int64_t)kbase + i + 3, i + 3);
+        }
+      }
+      flush(kbase, cnt);
+    }
   }
 
   // ---- epilogue

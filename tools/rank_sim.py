@@ -18,7 +18,18 @@ world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 sys.argv = ["bench.py"] + sys.argv[2:]
 o = bench.parse()
 dev = torch.device("cuda")
-parallel.all_gather_rows = lambda x, g: x.repeat(g.world, 1) if isinstance(g, parallel.DistGraph) and g.world > 1 else x
+
+
+def _fake_gather(x, g):
+    """N_global rows with this rank's own in place (other ranks' rows: copies - values do not matter for timing)."""
+    if not (isinstance(g, parallel.DistGraph) and g.world > 1):
+        return x
+    reps = -(-g.n_global // x.shape[0])
+    return x.repeat(reps, 1)[: g.n_global].contiguous()
+
+
+parallel.all_gather_rows = _fake_gather
+parallel.exchange = lambda x, g, edge_only: (_fake_gather(x, g), g)
 parallel.all_reduce_sum = lambda t, g: t
 a, enc, trainers, graph, x, lists = bench.build_workload(o, 0, world, dev)
 for _ in range(1):
