@@ -1,4 +1,6 @@
 """Host orchestration of the backward passes (csrc/edge_bwd.hip) for ops.EdgePass / ops.AuxPass."""
+import os
+
 import torch
 
 from . import _lib, ops
@@ -14,7 +16,7 @@ def _buf(shape, dev, zero):
 # Keys split across several work items (hub rows / columns): True = every slice writes its own partial record and
 # disgat_seg_combine adds them in slice order (run-to-run deterministic gradients); False = float atomics into zeroed
 # rows (the round-1 behaviour, kept for comparison).
-DETERMINISTIC = True
+DETERMINISTIC = os.environ.get("DISGAT_ATOMIC_BWD") != "1"
 
 
 def _keybuf(shape, dev, wi, force_zero=False):

@@ -216,3 +216,36 @@ def test_checkpoint_round_trip_uses_the_reference_layout(tmp_path):
     main.load_model(m2, a, root=str(tmp_path))
     for (k1, v1), (k2, v2) in zip(m1.state_dict().items(), m2.state_dict().items()):
         assert k1 == k2 and torch.equal(v1, v2)
+
+
+def test_conformT_restricts_disedge_groups_to_the_labelled_split():
+    """--conformT (pretrainer.py:465-498): only edges whose two endpoints are in the train + val split count as known
+    homo / hetero edges; without it every edge does (pretrainer.py:448-456).  Pure host logic: runs on the CPU."""
+    import random
+    from types import SimpleNamespace
+    from edgedisentangle_ssl_amd import pretrainer, sampling
+    from edgedisentangle_ssl_amd.graph import CSRGraph
+    from edgedisentangle_ssl_amd.utils import split
+    idx, _vals, n = ic.tiny_graph()
+    g = CSRGraph.from_index(idx, n)
+    labels = torch.arange(n) % 3
+    tr = pretrainer.GeneratedEdgeTrainer.__new__(pretrainer.GeneratedEdgeTrainer)
+    tr.dis_type = 1
+    tr.args = SimpleNamespace(conformT=False, node_sup_ratio=0.25)
+    homo, het = tr.get_label_all(None, g, labels)
+    flat = sampling.flat_edges(g)
+    same = labels[g.row] == labels[g.col.long()]
+    assert torch.equal(homo, flat[same]) and torch.equal(het, flat[~same]) and homo.numel() + het.numel() == g.nnz
+    tr.args.conformT = True
+    random.seed(11)
+    homo_c, het_c = tr.get_label_all(None, g, labels)
+    random.seed(11)
+    tr_i, va_i, _te, _m = split(labels, train_ratio=0.25)
+    known = torch.zeros(n, dtype=torch.bool)
+    known[torch.cat((tr_i, va_i))] = True
+    for sub, full in ((homo_c, homo), (het_c, het)):
+        assert torch.isin(sub, full).all() and sub.numel() < full.numel()
+        assert known[sub // n].all() and known[sub % n].all()
+    both = known[g.row] & known[g.col.long()]
+    assert homo_c.numel() == int((same & both).sum()) and het_c.numel() == int((~same & both).sum())
+    assert tr.n_pos_global == [homo_c.numel(), het_c.numel()]
