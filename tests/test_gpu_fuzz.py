@@ -20,4 +20,4 @@ def test_randomised_parity(seed):
         results = [fuzz_parity.one(c, rng) for c in range(30)]
     finally:
         ops.CHUNK = saved
-    assert sum(r == "ok" for r in results) >= 20, results
+    assert sum(r == "ok" for r in results) >= 27, results        # the rest: empty edge lists (the oracle is undefined there)
