@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void aux_att1_kernel(const AuxArgs A) {
 // label so the host can apply adj_mse_loss's class weights (utils.py:287-298):
 //   acc[0] += sum_{t!=0} (pred-t)^2, acc[1] += sum_{t==0} (pred-t)^2, acc[2] += #{t!=0}
 __global__ __launch_bounds__(256) void pair_loss_kernel(const float* __restrict__ aux, int64_t M, int h_lo, int h_hi,
-                                                        const float* __restrict__ labels, double* __restrict__ acc) {
+                                                        const float* __restrict__ labels, double* __restrict__ part) {
   double sp = 0.0, sn = 0.0, np_ = 0.0;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += stride) {
@@ -253,8 +253,17 @@ __global__ __launch_bounds__(256) void pair_loss_kernel(const float* __restrict_
   if (threadIdx.x < 3) {
     double t = 0.0;
     for (int w = 0; w < DISGAT_WAVES_PER_BLOCK; ++w) t += red[threadIdx.x][w];
-    atomicAdd(&acc[threadIdx.x], t);
+    part[(size_t)blockIdx.x * 3 + threadIdx.x] = t;         // one partial per block: the final sum runs in block order
   }
+}
+
+// acc[q] += sum over blocks of part[b][q], in block order (deterministic: no floating-point atomics anywhere in the loss)
+__global__ __launch_bounds__(64) void pair_loss_finish_kernel(const double* __restrict__ part, int n_blocks, double* __restrict__ acc) {
+  const int q = threadIdx.x;
+  if (q >= 3) return;
+  double t = 0.0;
+  for (int b = 0; b < n_blocks; ++b) t += part[(size_t)b * 3 + q];
+  acc[q] += t;
 }
 
 // Backward of the same loss: d loss / d aux[h][m] = coef[t_m != 0 ? 0 : 1] * 2 (p - t) p (1 - p) for h in [h_lo, h_hi), 0 for
@@ -378,14 +387,16 @@ extern "C" int disgat_aux_score(int att, const int64_t* pair_rows, const int64_t
 }
 
 extern "C" int disgat_pair_loss(const float* aux, int64_t M, int h_lo, int h_hi, const float* labels, double* acc,
-                                disgat_stream_t stream) {
+                                double* block_partials, disgat_stream_t stream) {
   using namespace disgat;
-  DISGAT_REQUIRE(aux && labels && acc && M >= 0 && h_lo >= 0 && h_hi >= h_lo, "pair_loss: bad arguments");
+  DISGAT_REQUIRE(aux && labels && acc && block_partials && M >= 0 && h_lo >= 0 && h_hi >= h_lo, "pair_loss: bad arguments");
   if (M == 0) return 0;
-  const int grid = (int)min((int64_t)2048, (M + 255) / 256);
-  hipLaunchKernelGGL(pair_loss_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), aux, M, h_lo,
-                     h_hi, labels, acc);
-  return check_launch("pair_loss_kernel");
+  const int grid = (int)min((int64_t)DISGAT_PAIR_LOSS_MAX_BLOCKS, (M + 255) / 256);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(pair_loss_kernel, dim3(grid), dim3(256), 0, st, aux, M, h_lo, h_hi, labels, block_partials);
+  if (int rc = check_launch("pair_loss_kernel")) return rc;
+  hipLaunchKernelGGL(pair_loss_finish_kernel, dim3(1), dim3(64), 0, st, block_partials, grid, acc);
+  return check_launch("pair_loss_finish_kernel");
 }
 
 extern "C" int disgat_pair_loss_bwd(const float* aux, int64_t M, int H, int h_lo, int h_hi, const float* labels,

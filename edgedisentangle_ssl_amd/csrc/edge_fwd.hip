@@ -49,6 +49,8 @@ struct EdgeFwdArgs {
   int sage_div;
   DropCfg drop;
   uint32_t* sign;       // att 3, optional: [E][64] sign words (disgat_common.h) for the backward pass
+  const float* e_in;    // optional [H][E]: added to the score before the sigmoid (partial scores of a head whose
+                        // features are spread over several launches: heads wider than one launch's 1024 features)
 };
 
 template <int ATT, int HL, int QN, int XN>
@@ -163,6 +165,7 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void edge_fwd_kernel(const EdgeFwd
     } else {
       e = s1r + b.s2;
     }
+    if (A.e_in != nullptr) e += A.e_in[(int64_t)myh * A.E + k];      // one address per head group: a broadcast load
     {
       const bool mine = (i & (GE - 1)) == ge;
       const int slot = i / GE;
@@ -372,7 +375,7 @@ extern "C" int disgat_edge_fwd(int att, const int32_t* items, int n_items, const
                                int F_in, int F_out, const float* x, int ldx, const float* rowop, int ld_row,
                                const float* colop, int ld_col, const float* a, float* Z, float* edge_e, float* den,
                                float* part_z, float* part_den, int sage_div, float drop_p, uint64_t drop_seed,
-                               uint32_t* sign_bits, disgat_stream_t stream) {
+                               uint32_t* sign_bits, const float* e_in, disgat_stream_t stream) {
   using namespace disgat;
   DISGAT_REQUIRE(att >= 1 && att <= 4, "edge_fwd: att=%d not in 1..3 (4 = att 2 over projected operands)", att);
   DISGAT_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "edge_fwd: dropout p=%f outside [0,1)", (double)drop_p);
@@ -400,7 +403,7 @@ extern "C" int disgat_edge_fwd(int att, const int32_t* items, int n_items, const
   EdgeFwdArgs args{reinterpret_cast<const int4*>(items), n_items, col, E, N, F_in, x, ldx, rowop, ld_row, colop, ld_col,
                    a, Z, edge_e, den, part_z, part_den, sage_div,
                    DropCfg{drop_seed, (uint32_t)((double)drop_p * 4294967296.0), 1.0f / (1.0f - drop_p)},
-                   att == 3 ? sign_bits : nullptr};
+                   att == 3 ? sign_bits : nullptr, e_in};
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   switch (att) {
     case 1: return launch_edge_h<1>(hl, qn, xn, args, s);

@@ -74,6 +74,7 @@ class CSRGraph:
         self.device = col.device
         self._items = {}
         self._transpose = None
+        self._pairs = None
 
     # ------------------------------------------------------------------ construction
     @staticmethod
@@ -106,6 +107,13 @@ class CSRGraph:
     def indices(self):
         """(2,E) int64 == adj.coalesce().indices()."""
         return torch.stack([self.row, self.col.to(torch.int64)])
+
+    def edge_pairs(self):
+        """The edge list as a pair list for the aux scorer (built once; in range by construction)."""
+        if self._pairs is None:
+            self._pairs = self.indices().contiguous()
+            self._pairs._disgat_in_range = True
+        return self._pairs
 
     # ------------------------------------------------------------------ work items
     def work_items(self, chunk):

@@ -122,6 +122,9 @@ class HeadList(list):
     pre_elu = None
 
 
+MAX_HEAD_SLICE = 1024      # att 3 / 4: features of one head a single launch scores (2 heads x 32 lanes x 8 float4)
+
+
 def _kernel_heads(att, Hp, f_out, f_in_p=0):
     """Heads per kernel launch (a power of two in [2,16]) and the padded per-head F_out for att 3.
 
@@ -168,7 +171,7 @@ def clear_weight_cache(module):
         m.__dict__.pop("_disgat_memo", None)
 
 
-def _pack_score_operands(layers, x, x_all, att, H, Hp, f_in, f_out, fp, am=None):
+def _pack_score_operands(layers, x, x_all, att, H, Hp, f_in, f_out, fp, am=None, cols=None):
     """Dense, differentiable (torch ops -> MFMA GEMMs) preparation of the per-node score operands.
     x: the rows this process owns; x_all: every node a column index can name (== x unsharded).
 
@@ -181,7 +184,11 @@ def _pack_score_operands(layers, x, x_all, att, H, Hp, f_in, f_out, fp, am=None)
                                 P = x W[:F_in], Q = x W[F_in:]                     -> [N,Hp*fp] each
     Returns (rowop, colop, a_vec); fp = padded per-head width of the att-3 operands.  am: max |x_all| as a device
     scalar (or None), the scale input of the f16x3 GEMMs (x's rows are a subset of x_all's, so it serves both).
+    cols = (c0, c1) (att 3 / 4): only output features [c0, c1) of every head - a head wider than MAX_HEAD_SLICE is scored
+    in feature slices whose partial scores add (the score is a sum over features).
     """
+    c0, c1 = (0, f_out) if cols is None else cols
+    fw = c1 - c0
     if att == 1:
         zero = [x.new_zeros(f_in)] * (Hp - H)
         w1 = torch.stack([l.W @ l.a[:f_out, 0] for l in layers] + zero, dim=1)     # [F_in, Hp]
@@ -191,10 +198,10 @@ def _pack_score_operands(layers, x, x_all, att, H, Hp, f_in, f_out, fp, am=None)
         # att 2 as the reference writes it (layers.py:362-365): h = x W per head, e = <h[r], h[c]>.  One operand table
         # serves both sides (column ids index the gathered x_all; unsharded, x_all is x and the GEMM runs once).
         def pack4():
-            wc = torch.cat([F.pad(l.W, (0, fp - f_out)) for l in layers] + [x.new_zeros(f_in, fp)] * (Hp - H), dim=1)
+            wc = torch.cat([F.pad(l.W[:, c0:c1], (0, fp - fw)) for l in layers] + [x.new_zeros(f_in, fp)] * (Hp - H), dim=1)
             return wc, ops_gemm.presplit(wc)
 
-        wc, sc = _memo(layers, ("att4", fp, Hp), pack4)
+        wc, sc = _memo(layers, ("att4", fp, Hp, c0, c1), pack4)
         hcol = ops_gemm.linear(x_all, wc, a_amax=am, w_split=sc)
         hrow = hcol if x_all is x else ops_gemm.linear(x, wc, a_amax=am, w_split=sc)
         return hrow, hcol, None
@@ -204,13 +211,13 @@ def _pack_score_operands(layers, x, x_all, att, H, Hp, f_in, f_out, fp, am=None)
         ms += [x.new_zeros(f_in, f_in_p)] * (Hp - H)
         return ops_gemm.linear(x, torch.cat(ms, dim=1), a_amax=am), None, None      # [N, Hp*F_in_p]
     def pack3():
-        tops = [F.pad(l.W[:f_in], (0, fp - f_out)) for l in layers] + [x.new_zeros(f_in, fp)] * (Hp - H)
-        bots = [F.pad(l.W[f_in:], (0, fp - f_out)) for l in layers] + [x.new_zeros(f_in, fp)] * (Hp - H)
-        a_vec = torch.cat([F.pad(l.a[:, 0], (0, fp - f_out)) for l in layers] + [x.new_zeros(fp)] * (Hp - H))
+        tops = [F.pad(l.W[:f_in, c0:c1], (0, fp - fw)) for l in layers] + [x.new_zeros(f_in, fp)] * (Hp - H)
+        bots = [F.pad(l.W[f_in:, c0:c1], (0, fp - fw)) for l in layers] + [x.new_zeros(f_in, fp)] * (Hp - H)
+        a_vec = torch.cat([F.pad(l.a[c0:c1, 0], (0, fp - fw)) for l in layers] + [x.new_zeros(fp)] * (Hp - H))
         wt, wb = torch.cat(tops, dim=1), torch.cat(bots, dim=1)
         return wt, wb, a_vec.contiguous(), ops_gemm.presplit(wt), ops_gemm.presplit(wb)
 
-    wt, wb, a_vec, st, sb = _memo(layers, ("att3", fp, Hp), pack3)
+    wt, wb, a_vec, st, sb = _memo(layers, ("att3", fp, Hp, c0, c1), pack3)
     return ops_gemm.linear(x, wt, a_amax=am, w_split=st), ops_gemm.linear(x_all, wb, a_amax=am, w_split=sb), a_vec
 
 
@@ -248,7 +255,15 @@ def disga_heads(layers, x, adj, aux_indices=None, head_ranges=None, aux_only=Fal
         # own formulation instead: per-head projections h = x W on both sides (kernel code 4), x aggregated in
         # column slices like att 1 / 3.
         att = 4
-    Hk, fp = _kernel_heads(att, Hp, f_out, f_in_p)   # heads per launch; Hp / Hk head groups
+    # A head wider than one launch covers (att 3 / 4: 1024 features) is scored in equal feature slices: the score is a
+    # sum over features, so the slices' partial scores add - all but the last slice run through the pair scorer on the
+    # graph's own edge list, the last one through the edge pass with the partial sum as an additive input (e_in).
+    f_slices = [(0, f_out)]
+    if att in (3, 4) and f_out > MAX_HEAD_SLICE:
+        n_sl = -(-f_out // MAX_HEAD_SLICE)
+        fs = -(-f_out // n_sl)
+        f_slices = [(k * fs, min(f_out, (k + 1) * fs)) for k in range(n_sl)]
+    Hk, fp = _kernel_heads(att, Hp, f_slices[0][1] - f_slices[0][0], f_in_p)   # heads per launch; Hp / Hk head groups
     n_groups = Hp // Hk
     # register tile of the edge pass: Hk * ceil(F_in/256) float4 accumulators <= 16.  Wider inputs (raw
     # bag-of-words features, --origin_feat) are aggregated in column slices; the scores of att 1 / 3 do
@@ -267,26 +282,40 @@ def disga_heads(layers, x, adj, aux_indices=None, head_ranges=None, aux_only=Fal
     # no precision (the scheme is exact to 2^-23 per element down to 2^-27 of the scale), only range.
     am_x = ops_gemm.amax_for(x_all)
     z_bound = None if am_x is None else am_x * (1.001 / (1.0 - drop[0]))
-    rowop, colop, a_vec = _pack_score_operands(layers, x, x_all, att, H, Hp, f_in, f_out, fp, am_x)
+    slice_ops = [_pack_score_operands(layers, x, x_all, att, H, Hp, f_in, f_out, fp, am_x,
+                                      cols=None if len(f_slices) == 1 else sl) for sl in f_slices]
+    rowop, colop, a_vec = slice_ops[-1]
     # per-head operand width inside a row of rowop / colop (att 1: one scalar, att 2: F_in_p, att 3: fp)
     w_row = {1: 1, 2: f_in_p, 3: fp, 4: fp}[att]
 
-    def group_ops(gi):
+    def group_ops(gi, si=-1):
         lo = gi * Hk * w_row
         hi = lo + Hk * w_row
-        r = rowop[:, lo:hi]
-        c = None if colop is None else colop[:, lo:hi]
-        av = None if a_vec is None else a_vec[lo:hi]
+        ro, co, avec = slice_ops[si]
+        r = ro[:, lo:hi]
+        c = None if co is None else co[:, lo:hi]
+        av = None if avec is None else avec[lo:hi]
         d = (drop[0], drop[1] + 0x9E3779B1 * gi) if drop[0] > 0 else drop      # independent masks per group
         return r, c, av, d
 
     rec = ops.wants_sign(att, rowop, colop, a_vec)     # att 3: record lrelu signs for a gather-free backward
+
+    def earlier_slices(gi, pairs, g_lo, g_hi):
+        """Sum over all but the last feature slice of the partial scores of `pairs` (heads [g_lo, g_hi) of group gi);
+        None for ordinary heads (one slice)."""
+        tot = None
+        for si in range(len(f_slices) - 1):
+            r_, c_, av_, _d = group_ops(gi, si)
+            part = ops.AuxPass.apply(None, r_, c_, av_, pairs, (att, Hk, f_in_p, fp, graph.n, g_lo, g_hi, rec))
+            tot = part[g_lo:g_hi] if tot is None else tot + part[g_lo:g_hi]
+        return tot
+
     if aux_indices is not None and not isinstance(aux_indices, list):
         aux_indices = [aux_indices]
     # differentiable att-3 layer with aux lists, one head group, no column slices (the training configuration): the edge
     # pass and all aux lists form ONE autograd node, so P / Q / a get one gradient each (ops.LayerPass)
     merged_aux = None
-    merge = rec and not aux_only and aux_indices and n_groups == 1 and f_in_p <= tile
+    merge = rec and not aux_only and aux_indices and n_groups == 1 and f_in_p <= tile and len(f_slices) == 1
     heads = e_list = None
     if not aux_only:
         z_groups, e_groups = [], []
@@ -299,13 +328,15 @@ def disga_heads(layers, x, adj, aux_indices=None, head_ranges=None, aux_only=Fal
                 z, edge_e, _den, *merged_aux = ops.LayerPass.apply(xg, r, c, av, cfg, *aux_indices)
             elif f_in_p <= tile:
                 cfg = (graph, att, Hk, f_in_p, fp, gnn == "SAGE", d, rec)
-                z, edge_e, _den = ops.EdgePass.apply(xg, r, c, av, cfg)
+                e_in = earlier_slices(gi, graph.edge_pairs(), 0, Hk) if len(f_slices) > 1 else None
+                z, edge_e, _den = ops.EdgePass.apply(xg, r, c, av, cfg, e_in)
             else:
                 zs, edge_e = [], None
+                e_in = earlier_slices(gi, graph.edge_pairs(), 0, Hk) if len(f_slices) > 1 else None
                 for c0 in range(0, f_in_p, tile):
                     c1 = min(f_in_p, c0 + tile)
                     cfg = (graph, att, Hk, c1 - c0, fp, gnn == "SAGE", d, rec)
-                    zc, ec, _den = ops.EdgePass.apply(xg[:, c0:c1], r, c, av, cfg)
+                    zc, ec, _den = ops.EdgePass.apply(xg[:, c0:c1], r, c, av, cfg, e_in)
                     zs.append(zc)
                     edge_e = ec if edge_e is None else edge_e
                 z = torch.cat(zs, dim=2)
@@ -365,6 +396,10 @@ def disga_heads(layers, x, adj, aux_indices=None, head_ranges=None, aux_only=Fal
                 r, c, av, _d = group_ops(gi)
                 acfg = (att, Hk, f_in_p, fp, graph.n, g_lo - gi * Hk, g_hi - gi * Hk, rec)
                 out = ops.AuxPass.apply(xg if att == 2 else None, r, c, av, pairs, acfg)
+                if len(f_slices) > 1:          # wide heads: the other feature slices' partial scores
+                    out = torch.cat([out[: g_lo - gi * Hk],
+                                     out[g_lo - gi * Hk: g_hi - gi * Hk] + earlier_slices(gi, pairs, g_lo - gi * Hk, g_hi - gi * Hk),
+                                     out[g_hi - gi * Hk:]])
                 for h in range(g_lo, g_hi):
                     per_head[h] = out[h - gi * Hk].unsqueeze(1)
             per_list.append(per_head)

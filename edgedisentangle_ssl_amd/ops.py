@@ -85,13 +85,18 @@ def _row_major(t, name):
 
 
 def edge_forward(graph: CSRGraph, att, H, F_in, F_out, x, rowop, colop, a, sage_div, drop=(0.0, 0), need_den=True,
-                 sign=None):
+                 sign=None, e_in=None):
     """Launch disgat_edge_fwd (+ disgat_edge_combine for split rows).
 
     x [N, >=F_in] (row stride % 4 == 0), rowop/colop 2-D views with unit inner
     stride, a [H*F_out] or None; drop = (p, seed) of the attention dropout; sign: optional
-    sign_record(...) buffer the att-3 kernel fills.  Returns Z [N,H,F_in], edge_e [H,E], den [N,2,H].
+    sign_record(...) buffer the att-3 kernel fills; e_in: optional contiguous [H,E] partial scores added before the
+    sigmoid.  Returns Z [N,H,F_in], edge_e [H,E], den [N,2,H].
     """
+    if e_in is not None:
+        _check(e_in, "e_in")
+        if tuple(e_in.shape) != (H, graph.nnz) or not e_in.is_contiguous():
+            raise RuntimeError("e_in must be a contiguous [H,E] tensor")
     for t, nm in ((x, "x"), (rowop, "rowop")) + (((colop, "colop"),) if colop is not None else ()):
         _check(t, nm)
         _row_major(t, nm)
@@ -110,7 +115,7 @@ def edge_forward(graph: CSRGraph, att, H, F_in, F_out, x, rowop, colop, a, sage_
             att, _ptr(wi.items), wi.n_items, _ptr(graph.col), e, n, H, F_in, F_out,
               _ptr(x), x.stride(0), _ptr(rowop), rowop.stride(0), _ptr(colop), 0 if colop is None else colop.stride(0),
               _ptr(a), _ptr(z), _ptr(edge_e), _ptr(den), _ptr(part_z), _ptr(part_den), int(bool(sage_div)),
-              float(drop[0]), int(drop[1]), _ptr(sign), st)
+              float(drop[0]), int(drop[1]), _ptr(sign), _ptr(e_in), st)
     if wi.n_split:
         _lib.call("disgat_edge_combine", _ptr(wi.split_rows), _ptr(wi.split_ptr), wi.n_split, H, F_in,
                   _ptr(part_z), _ptr(part_den), _ptr(z), _ptr(den), int(bool(sage_div)), st)
@@ -169,19 +174,23 @@ def pair_loss_sums(aux, h_lo, h_hi, labels):
     acc = torch.zeros(3, dtype=torch.float64, device=aux.device)
     if aux.stride(1) != 1 or aux.stride(0) != aux.shape[1]:
         raise RuntimeError("aux must be a contiguous [H,M] tensor")
-    _lib.call("disgat_pair_loss", _ptr(aux), int(aux.shape[1]), h_lo, h_hi, _ptr(labels.contiguous()), _ptr(acc), _stream())
+    part = torch.empty((2048, 3), dtype=torch.float64, device=aux.device)      # DISGAT_PAIR_LOSS_MAX_BLOCKS per-block sums
+    _lib.call("disgat_pair_loss", _ptr(aux), int(aux.shape[1]), h_lo, h_hi, _ptr(labels.contiguous()), _ptr(acc), _ptr(part),
+              _stream())
     return acc
 
 
 class EdgePass(torch.autograd.Function):
-    """Differentiable wrapper of edge_forward.  Non-tensor config travels in `cfg`."""
+    """Differentiable wrapper of edge_forward.  Non-tensor config travels in `cfg`; e_in: optional [H,E] partial
+    scores (its gradient is the total score gradient)."""
 
     @staticmethod
-    def forward(ctx, x, rowop, colop, a, cfg):
+    def forward(ctx, x, rowop, colop, a, cfg, e_in=None):
         graph, att, H, F_in, F_out, sage, drop = cfg[:7]
         ctx.sign = sign_record(att, H, F_out, graph.nnz, x.device) if (len(cfg) > 7 and cfg[7] and graph.nnz) else None
-        z, edge_e, den = edge_forward(graph, att, H, F_in, F_out, x, rowop, colop, a, sage, drop, sign=ctx.sign)
+        z, edge_e, den = edge_forward(graph, att, H, F_in, F_out, x, rowop, colop, a, sage, drop, sign=ctx.sign, e_in=e_in)
         ctx.cfg = cfg[:7]
+        ctx.has_e_in = e_in is not None
         ctx.save_for_backward(x, rowop, colop, a, z, edge_e, den)
         ctx.mark_non_differentiable(den)
         return z, edge_e, den
@@ -189,7 +198,8 @@ class EdgePass(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gz, ge, _gden):
         from . import ops_bwd
-        return ops_bwd.edge_backward(ctx, gz, ge)
+        out = ops_bwd.edge_backward(ctx, gz, ge, want_ge=ctx.has_e_in and ctx.needs_input_grad[5])
+        return out[:5] + (out[5],)
 
 
 class AuxPass(torch.autograd.Function):

@@ -79,14 +79,16 @@ def _seg_hx(col_mode, wi, other, perm, coef, lo, hi, H, f, otherop, gkey, accumu
     _combine(wi, part, gkey, f if col_mode else H * f, accumulate)
 
 
-def edge_backward(ctx, gz, ge):
+def edge_backward(ctx, gz, ge, want_ge=False):
+    """Returns (g_x, g_rowop, g_colop, g_a, None, ge_tot or None): the last entry is the total gradient of the raw
+    scores [H,E] (= the gradient of an additive e_in input), only when want_ge."""
     x, rowop, colop, a, z, edge_e, den = ctx.saved_tensors
     graph, att, H, f_in, f_out, sage, drop = ctx.cfg
     need_x, need_row, need_col, need_a = ctx.needs_input_grad[:4]
     dev = x.device
     n, e = graph.n, graph.nnz
     if e == 0:                      # no edges: Z == 0 and no score exists, every gradient is zero
-        return None, None, None, None, None
+        return None, None, None, None, None, None
     chunk = ops.CHUNK[att]
     wi = graph.work_items(chunk)
     gz = torch.zeros_like(z) if gz is None else gz.contiguous()
@@ -134,7 +136,7 @@ def edge_backward(ctx, gz, ge):
         _seg_hx(1, twi, t.col, t.eid, beta, 0, H, H, f_in, gz.view(n, H * f_in), g_x, False)   # n rows of gZ, g_x over all columns
         if att == 2:                                    # e = <P[r,h,:], x[c,:]>  ->  gx[c] += sum_h ge_kh P[r_k,h,:]
             _seg_hx(1, twi, t.col, t.eid, ge_tot, 0, H, H, f_in, rowop, g_x, True)
-    return g_x, g_row, g_col, g_a, None
+    return g_x, g_row, g_col, g_a, None, (ge_tot if want_ge else None)
 
 
 _SEG_CACHE = {}          # (storage ptr, M, version, side, n_keys, chunk) -> (pairs kept alive, result); FIFO of 8
@@ -238,7 +240,7 @@ def layer_backward(ctx, gz, ge, gaux):
     if (gz is not None or ge is not None) and graph.nnz:
         ectx = SimpleNamespace(saved_tensors=(x, rowop, colop, a, z, edge_e, den), cfg=(graph, att, H, f_in, f_out, sage, drop),
                                needs_input_grad=ctx.needs_input_grad, sign=ctx.sign)
-        g_x, g_row, g_col, g_a, _ = edge_backward(ectx, gz, ge)
+        g_x, g_row, g_col, g_a, _, _ge = edge_backward(ectx, gz, ge)
     chunk = ops.CHUNK[att]
     n_rows, n_cols = rowop.shape[0], colop.shape[0]
     for pairs, (lo, hi), sign, gout in zip(lists, ranges, ctx.aux_signs, gaux):

@@ -73,7 +73,9 @@ typedef void* disgat_stream_t; /* hipStream_t */
 int disgat_abi_version(void);
 const char* disgat_last_error(void);
 
-/* Fused score -> sigmoid -> row softmax -> aggregation for all H heads of one layer. */
+/* Fused score -> sigmoid -> row softmax -> aggregation for all H heads of one layer.
+ * e_in (or NULL): [H][E] partial scores added before the sigmoid - a head wider than one launch's 1024 features is
+ * scored in feature slices (disgat_aux_score on the edge list for all but the last slice); edge_e receives the total. */
 int disgat_edge_fwd(int att, const int32_t* items, int n_items, const int32_t* col, int64_t E,
                     int N, int H, int F_in, int F_out,
                     const float* x, int ldx,
@@ -83,7 +85,7 @@ int disgat_edge_fwd(int att, const int32_t* items, int n_items, const int32_t* c
                     float* Z, float* edge_e, float* den,
                     float* part_z, float* part_den,
                     int sage_div, float drop_p, uint64_t drop_seed,
-                    uint32_t* sign_bits, disgat_stream_t stream);
+                    uint32_t* sign_bits, const float* e_in, disgat_stream_t stream);
 
 /* Sums the partial records of split rows (in chunk order: deterministic) and normalises. */
 int disgat_edge_combine(const int32_t* split_rows, const int32_t* split_ptr, int n_split,
@@ -101,9 +103,11 @@ int disgat_aux_score(int att, const int64_t* pair_rows, const int64_t* pair_cols
 
 /* Weighted squared-error partial sums of pred = sigmoid(sum_{h in [h_lo,h_hi)} aux[h][m])
  * against 0/1 labels: acc[0] += sum over positives, acc[1] += sum over zeros, acc[2] += #positives.
- * acc (3 doubles) must be zeroed by the caller. */
+ * acc (3 doubles) must be zeroed by the caller; block_partials: scratch for DISGAT_PAIR_LOSS_MAX_BLOCKS x 3 doubles
+ * (per-block sums, added in block order by a second tiny launch: the value is run-to-run deterministic). */
+#define DISGAT_PAIR_LOSS_MAX_BLOCKS 2048
 int disgat_pair_loss(const float* aux, int64_t M, int h_lo, int h_hi, const float* labels,
-                     double* acc, disgat_stream_t stream);
+                     double* acc, double* block_partials, disgat_stream_t stream);
 
 /* ---- backward -------------------------------------------------------------------------- */
 

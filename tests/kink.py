@@ -23,7 +23,12 @@ def record_operands(store):
 
     def wrapped(*a, **k):
         out = orig(*a, **k)
-        store.append((out[0].detach(), out[1].detach() if out[1] is not None else None))
+        cols = k.get("cols")
+        entry = (out[0].detach(), out[1].detach() if out[1] is not None else None, cols)
+        if cols is None or cols[0] == 0:
+            store.append([entry])               # a new layer (one entry per feature slice of its heads)
+        else:
+            store[-1].append(entry)
         return out
     layers._pack_score_operands = wrapped
     try:
@@ -33,8 +38,9 @@ def record_operands(store):
 
 
 class Pins:
-    """operands: one (rowop [N, Hp*fp], colop [N_all, Hp*fp]) per layer, in call order; lists: the (rows, cols) index
-    lists the oracle scores per head, in its call order (edges first, then every aux list)."""
+    """operands: per layer (in call order) the list of its feature slices' (rowop [N, Hp*fp], colop [N_all, Hp*fp],
+    (c0, c1) or None) as record_operands() stores them; lists: the (rows, cols) index lists the oracle scores per
+    head, in its call order (edges first, then every aux list)."""
 
     def __init__(self, operands, n_heads, f_out, lists, thr=1e-5):
         self.ops, self.H, self.f_out, self.lists, self.thr = operands, n_heads, f_out, lists, thr
@@ -48,13 +54,16 @@ class Pins:
         per_layer = self.H * len(self.lists)
         layer, rem = divmod(k, per_layer)
         h, li = divmod(rem, len(self.lists))
-        rowop, colop = self.ops[layer]
         hp = max(2, 1 << (self.H - 1).bit_length())
-        fp = rowop.shape[1] // hp
         r, c = self.lists[li]
-        dev = rowop.device
-        sl = slice(h * fp, h * fp + self.f_out)
-        pos32 = ((rowop[:, sl][r.to(dev)] + colop[:, sl][c.to(dev)]) > 0).cpu()
+        parts = []
+        for rowop, colop, cols in self.ops[layer]:          # one entry, or one per feature slice of a wide head
+            fp = rowop.shape[1] // hp
+            width = self.f_out if cols is None else cols[1] - cols[0]
+            dev = rowop.device
+            sl = slice(h * fp, h * fp + width)
+            parts.append(((rowop[:, sl][r.to(dev)] + colop[:, sl][c.to(dev)]) > 0).cpu())
+        pos32 = parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
         zd = z.detach()
         near = zd.abs() < self.thr
         self.pinned += int(near.sum())

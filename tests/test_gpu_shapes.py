@@ -26,6 +26,8 @@ CASES = [
     # att 2 wider than its register tile (F_in > 512, e.g. Cora's raw 1 433-wide bag of words with --origin_feat):
     # scored through the per-head projections h = x W (kernel code 4), x aggregated in column slices
     (4, 1433, 16, 2, "AT"), (8, 700, 32, 2, "SAGE"), (3, 520, 70, 2, "GCN"), (20, 600, 24, 2, "AT"),
+    # a single head wider than one launch scores (1024 features): feature slices, partial scores added through e_in
+    (2, 40, 2048, 3, "AT"), (1, 24, 1500, 3, "GCN"), (3, 600, 1100, 2, "SAGE"), (5, 300, 1030, 3, "SAGE"),
 ]
 
 
