@@ -185,6 +185,11 @@ def build_workload(o, rank, world, dev):
         x = synth.features(o.nodes, o.feat, dev, seed=rank)
     graph.work_items(ops.CHUNK[o.att])        # CSR preprocessing (work items): untimed, reported separately
     graph.prep_ms = prep_ms
+    if world > 1:
+        # the feature matrix is a constant of the run: its all-gathered form is exchanged once, not once per encoder
+        # pass (parallel.mark_static; layer 2's input is a fresh tensor every pass and is exchanged every time)
+        from edgedisentangle_ssl_amd import parallel
+        parallel.mark_static(x)
     return a, enc, (sup, dis, dif), graph, x, lists
 
 

@@ -102,6 +102,9 @@ def run(argv=None, log=print):
     args.size = features.shape[1]
     args.nclass = labels.max().item() + 1
     labels = labels.to(dev)
+    if world > 1:
+        from . import parallel
+        parallel.mark_static(features)       # exchanged once, reused by every pass that does not drop out its input
 
     encoder = models.DISGAT(args, nfeat=args.size, nhid=args.nhid, nclass=args.nhid, nheads=args.nhead,
                             dropout=args.dropout).to(dev)                  # main.py:142-147

@@ -94,6 +94,19 @@ def _worker(rank, world, port, q):
         xa3, g3 = parallel.exchange(xl.detach(), dg, edge_only=True)
         assert g3 is dg and torch.equal(xa3, x)
         os.environ.pop("DISGAT_EXCHANGE")
+        # a tensor marked static is gathered once: the second exchange is served from the graph, until it changes
+        xs = x[lo:lo + dg.n].clone()
+        parallel.mark_static(xs)
+        g1, _ = parallel.exchange(xs, dg, edge_only=False)
+        g2, _ = parallel.exchange(xs, dg, edge_only=False)
+        assert g2.data_ptr() == g1.data_ptr() and torch.equal(g1, x)            # same buffer: nothing was exchanged
+        xs.mul_(2.0)                                                # version bump: the stale copy must not be served
+        g3, _ = parallel.exchange(xs, dg, edge_only=False)
+        assert g3.data_ptr() != g1.data_ptr() and torch.equal(g3, x * 2.0)
+        xr = xs.clone().requires_grad_(True)                        # never for tensors a gradient is asked of
+        parallel.mark_static(xr)
+        g4, _ = parallel.exchange(xr, dg, edge_only=False)
+        assert g4.requires_grad and dg._static_gather[1].data_ptr() != g4.data_ptr()
 
         # global pair loss from per-rank partial sums (what pretrainer.pair_mse_loss reduces)
         pairs, lab = ic.sample_pairs(31, n, np.sort((g.row * n + g.col.long()).numpy()), "sup")
