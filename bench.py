@@ -412,7 +412,8 @@ def launch_ranks(o):
             p.kill()
             p.wait()
             rc = rc or 1
-    sys.stdout.write(out)
+    for line in out.splitlines():          # stdout carries the ONE JSON line; anything else a library printed -> stderr
+        (sys.stdout if line.startswith("{") else sys.stderr).write(line + "\n")
     sys.stdout.flush()
     return rc
 
