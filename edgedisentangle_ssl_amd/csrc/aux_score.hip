@@ -257,13 +257,15 @@ __global__ __launch_bounds__(256) void pair_loss_kernel(const float* __restrict_
   }
 }
 
-// acc[q] += sum over blocks of part[b][q], in block order (deterministic: no floating-point atomics anywhere in the loss)
-__global__ __launch_bounds__(64) void pair_loss_finish_kernel(const double* __restrict__ part, int n_blocks, double* __restrict__ acc) {
-  const int q = threadIdx.x;
-  if (q >= 3) return;
+// acc[q] += sum over blocks of part[b][q] in a FIXED order (lane l adds blocks l, l+64, ... in sequence, then a fixed
+// shuffle tree): deterministic, no floating-point atomics anywhere in the loss.  One wave per quantity.
+__global__ __launch_bounds__(192) void pair_loss_finish_kernel(const double* __restrict__ part, int n_blocks, double* __restrict__ acc) {
+  const int q = threadIdx.x >> 6, lane = threadIdx.x & 63;
   double t = 0.0;
-  for (int b = 0; b < n_blocks; ++b) t += part[(size_t)b * 3 + q];
-  acc[q] += t;
+  for (int b = lane; b < n_blocks; b += 64) t += part[(size_t)b * 3 + q];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+  if (lane == 0) acc[q] += t;
 }
 
 // Backward of the same loss: d loss / d aux[h][m] = coef[t_m != 0 ? 0 : 1] * 2 (p - t) p (1 - p) for h in [h_lo, h_hi), 0 for
@@ -395,7 +397,7 @@ extern "C" int disgat_pair_loss(const float* aux, int64_t M, int h_lo, int h_hi,
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(pair_loss_kernel, dim3(grid), dim3(256), 0, st, aux, M, h_lo, h_hi, labels, block_partials);
   if (int rc = check_launch("pair_loss_kernel")) return rc;
-  hipLaunchKernelGGL(pair_loss_finish_kernel, dim3(1), dim3(64), 0, st, block_partials, grid, acc);
+  hipLaunchKernelGGL(pair_loss_finish_kernel, dim3(1), dim3(192), 0, st, block_partials, grid, acc);
   return check_launch("pair_loss_finish_kernel");
 }
 
