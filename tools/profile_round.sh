@@ -8,7 +8,7 @@ ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 OUT="$ROOT/gpurun_out/${1:-r02/prof}"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-B="python3 $ROOT/bench.py --no-cpu-baseline --steps 3 --warmup 1"
+B="python3 $ROOT/bench.py --no-cpu-baseline --no-secondary --steps 3 --warmup 1"
 run() { # name, rocprof-args..., -- program...
   local name=$1; shift
   echo "[profile] $name"; date +%T
@@ -21,6 +21,7 @@ run kt_c4_att1   --kernel-trace --stats --output-format csv -d "$OUT/kt_c4_att1"
 run kt_c4_att2   --kernel-trace --stats --output-format csv -d "$OUT/kt_c4_att2"   -- $B --att 2 &&
 run kt_c3_sage   --kernel-trace --stats --output-format csv -d "$OUT/kt_c3_sage"   -- $B --nodes 100000 --edges 2000000 --feat 128 --gnn_type SAGE &&
 run kt_c4_fwd    --kernel-trace --stats --output-format csv -d "$OUT/kt_c4_fwd"    -- $B --fwd-only &&
+run kt_c4_train  --kernel-trace --stats --output-format csv -d "$OUT/kt_c4_train"  -- python3 $ROOT/tools/train_bench.py --nodes 1000000 --edges 20000000 &&
 for shape in "256 2048" "2048 256"; do
   tag="gemm_$(echo $shape | tr ' ' 'x')"
   run ${tag}_sq1 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_LDS --output-format csv -d "$OUT/${tag}_sq1" -- python3 $ROOT/tools/gemm_one.py $shape &&
@@ -30,6 +31,10 @@ for shape in "256 2048" "2048 256"; do
   run ${tag}_kt --kernel-trace --stats --output-format csv -d "$OUT/${tag}_kt" -- python3 $ROOT/tools/gemm_one.py $shape || break
 done
 echo "[profile] done"; date +%T
-# keep what travels back small: the per-dispatch trace CSVs can be tens of MB
-find "$OUT" -name "*kernel_trace.csv" -size +4M -delete
-du -sh "$OUT"
+# keep what travels back small (gpurun merges at most 64 MiB): the per-dispatch traces are not needed (the stats files
+# are), and of the per-dispatch counter rows only this library's kernels are
+find "$OUT" -name "*kernel_trace.csv" -delete
+for f in $(find "$OUT" -name "*counter_collection.csv"); do
+  { head -1 "$f"; grep disgat "$f"; } > "$f.tmp" && mv "$f.tmp" "$f"
+done
+du -sh "$OUT"; du -a "$OUT" | sort -n | tail -5

@@ -15,6 +15,8 @@ NOTES = {
     "kt_c4_att2": "bench.py --att 2 (same graph)",
     "kt_c3_sage": "bench.py --nodes 100000 --edges 2000000 --feat 128 --gnn_type SAGE (BASELINE configs[2])",
     "kt_c4_fwd": "bench.py --fwd-only (T_fwd = one get_em per step)",
+    "kt_c4_train": "tools/train_bench.py --nodes 1000000 --edges 20000000: 4 forward-only T_iter (eval) + 4 full training "
+                   "iterations (SupEdge + DisEdge + DifHead: forward, backward, multi-tensor Adam; attention dropout 0.1)",
 }
 
 
@@ -45,7 +47,11 @@ def main(src, dst):
             P = lambda *a: print(*a, file=out)      # noqa: E731
             P(f"# rocprofv3 --kernel-trace --stats: {tag}\n\n{note}\n")
             tot = sum(int(r["TotalDurationNs"]) for r in rows)
-            P(f"Total kernel time {tot / 1e6:.1f} ms over all 4 steps (1 warm-up + 3 timed)\n")
+            P(f"Total kernel time {tot / 1e6:.1f} ms over all steps of the run (bench.py: 1 warm-up + 3 timed)\n")
+            for line in open(os.path.join(src, tag + ".log"), errors="ignore"):
+                if "ms/iter" in line:
+                    P("    " + line.rstrip())
+            P("")
             P("| kernel | calls | total ms | avg ms | % |\n|---|---|---|---|---|")
             for r in rows[:16]:
                 P(f"| `{r['Name'][:100]}` | {r['Calls']} | {int(r['TotalDurationNs']) / 1e6:.2f} | "
