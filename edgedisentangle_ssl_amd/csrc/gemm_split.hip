@@ -554,12 +554,37 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x3_as_kernel(const GemmHArgs G
 
   const int KT = K / GBK;
   const int a_off = (lane & 15) * KP + (lane >> 4) * 8;            // + i*16*KP + t*32 (+ plane)
-  const int64_t b_off = (int64_t)(lane & 15) * K + (lane >> 4) * 8;  // + (n + j*16)*K + t*32 (+ plane N*K)
+  const int64_t b_off = (int64_t)lane * 8;                            // fragment-major planes: + ((n/16 + j)*KT + t)*512 (+ plane N*K)
   const int64_t b_plane = (int64_t)G.N * K;
 
-  for (int ns = 0; ns * 256 < G.N; ++ns) {
+  // Blocks walk the column steps in rotated order (block b starts at step b mod n_steps): every block streams the SAME
+  // weight planes from its XCD's L2, and blocks that start together would otherwise ask for the same lines at the same
+  // time, all on one L2 channel
+  const int n_steps = (G.N + 255) / 256;
+  const int rot = blockIdx.x % n_steps;
+  // The first k-step's weight fragments of a column step are requested BEFORE the previous step's results are stored:
+  // gfx9's vmcnt counts loads and stores in issue order, so a fragment load issued after the 16 stores could only be
+  // waited for by waiting for those stores to be acknowledged by memory - every step began with a full store drain.
+  f16x8 bh_n[2], bl_n[2];
+  auto first_frags = [&](int it_) {
+    const int n_w_ = ((it_ + rot) % n_steps) * 256 + wave * 32;
+    if (it_ < n_steps && n_w_ < G.N) {
+      const uint16_t* bp_ = Bt + (int64_t)(n_w_ >> 4) * KT * 512 + b_off;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        bh_n[j] = *reinterpret_cast<const f16x8*>(bp_ + (int64_t)j * KT * 512);
+        bl_n[j] = *reinterpret_cast<const f16x8*>(bp_ + b_plane + (int64_t)j * KT * 512);
+      }
+    }
+  };
+  first_frags(0);
+  for (int it = 0; it < n_steps; ++it) {
+    const int ns = (it + rot) % n_steps;
     const int n_w = ns * 256 + wave * 32;
-    if (n_w >= G.N) break;                                          // N % 256 == 128: waves 4-7 idle in the last step
+    if (n_w >= G.N) {                                               // N % 256 == 128: waves 4-7 idle in the last step
+      first_frags(it + 1);
+      continue;
+    }
     // bias and the additive init matrix seed the hi*hi accumulator (times s_A s_B, a power of two: exact) instead
     // of being added per element in the epilogue, where 64 dependent loads per lane sat between the stores
     f32x4v acc[8][2], acx[8][2];
@@ -585,13 +610,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x3_as_kernel(const GemmHArgs G
         }
       }
     }
-    const uint16_t* bp = Bt + (int64_t)n_w * K + b_off;
-    f16x8 bh_n[2], bl_n[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      bh_n[j] = *reinterpret_cast<const f16x8*>(bp + (int64_t)j * 16 * K);
-      bl_n[j] = *reinterpret_cast<const f16x8*>(bp + b_plane + (int64_t)j * 16 * K);
-    }
+    const uint16_t* bp = Bt + (int64_t)(n_w >> 4) * KT * 512 + b_off;
     for (int t = 0; t < KT; ++t) {
       f16x8 bh[2], bl[2];
 #pragma unroll
@@ -602,8 +621,8 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x3_as_kernel(const GemmHArgs G
       if (t + 1 < KT) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          bh_n[j] = *reinterpret_cast<const f16x8*>(bp + (int64_t)j * 16 * K + (t + 1) * GBK);
-          bl_n[j] = *reinterpret_cast<const f16x8*>(bp + b_plane + (int64_t)j * 16 * K + (t + 1) * GBK);
+          bh_n[j] = *reinterpret_cast<const f16x8*>(bp + (int64_t)(j * KT + t + 1) * 512);
+          bl_n[j] = *reinterpret_cast<const f16x8*>(bp + b_plane + (int64_t)(j * KT + t + 1) * 512);
         }
       }
 #pragma unroll
@@ -653,6 +672,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x3_as_kernel(const GemmHArgs G
     // per-lane pointers (rows +0 and +8 of each 16-row tile) advanced by the uniform row stride - one 64-bit add per
     // store, no multiplies; the activation is a template parameter (a run-time switch evaluated every branch for every
     // element); ragged last tiles take the checked copy of the loop.
+    first_frags(it + 1);                       // next step's first fragments: in flight before the stores below
     const bool full = m0 + AS_BM <= G.M;
     int64_t ldc = G.ldc;
     asm volatile("" : "+s"(ldc));
@@ -840,7 +860,7 @@ __global__ __launch_bounds__(256) void wamax_kernel(const float* __restrict__ W,
 
 __global__ __launch_bounds__(256) void wsplit_kernel(const float* __restrict__ W, int64_t sb, int64_t sk, int64_t sn, int K,
                                                      int N, int64_t total, const float* __restrict__ amax,
-                                                     uint16_t* __restrict__ planes, float* __restrict__ scale_out) {
+                                                     uint16_t* __restrict__ planes, float* __restrict__ scale_out, int frag) {
   const float s = f16_scale(*amax);
   if (blockIdx.x == 0 && threadIdx.x == 0) *scale_out = s;
   const int64_t kn = (int64_t)K * N;
@@ -850,8 +870,11 @@ __global__ __launch_bounds__(256) void wsplit_kernel(const float* __restrict__ W
     const float t = W[b * sb + k * sk + n * sn] * s;
     const _Float16 h = (_Float16)t;
     const _Float16 l = (_Float16)((t - (float)h) * 2048.f);
-    planes[(b * 2 + 0) * kn + r] = *reinterpret_cast<const uint16_t*>(&h);
-    planes[(b * 2 + 1) * kn + r] = *reinterpret_cast<const uint16_t*>(&l);
+    // K <= 256 (operands of the A-stationary kernel): fragment-major - the 16 x 32 block of (n-tile, k-step) is stored
+    // in MFMA lane order (lane = 16*(k%32/8) + n%16, 8 halfs each), so a wave's fragment load is one contiguous KB
+    const int64_t o = frag ? ((((n >> 4) * (K >> 5) + (k >> 5)) * 64 + (((k & 31) >> 3) << 4) + (n & 15)) << 3) + (k & 7) : r;
+    planes[(b * 2 + 0) * kn + o] = *reinterpret_cast<const uint16_t*>(&h);
+    planes[(b * 2 + 1) * kn + o] = *reinterpret_cast<const uint16_t*>(&l);
   }
 }
 
@@ -967,8 +990,10 @@ extern "C" int disgat_split_f16(const float* W, int64_t stride_b, int64_t stride
   const int grid = (int)(total / 256 + 1 < 1024 ? total / 256 + 1 : 1024);
   hipLaunchKernelGGL(wamax_kernel, dim3(grid), dim3(256), 0, st, W, stride_b, stride_k, stride_n, K, N, total,
                      reinterpret_cast<uint32_t*>(amax_scale));
+  // layout rule shared with disgat_gemm_f16x3: K <= 256 selects its A-stationary kernel, which reads fragment-major planes
+  const int frag = (K <= 256 && K % 32 == 0 && N % 16 == 0) ? 1 : 0;
   hipLaunchKernelGGL(wsplit_kernel, dim3(grid), dim3(256), 0, st, W, stride_b, stride_k, stride_n, K, N, total, amax_scale,
-                     planes, amax_scale + 1);
+                     planes, amax_scale + 1, frag);
   return check_launch("wsplit_kernel");
 }
 

@@ -201,8 +201,11 @@ int disgat_amax(const float* A, int64_t lda, int64_t a_batch_stride, int M, int 
                 disgat_stream_t stream);
 
 /* Weight preparation for disgat_gemm_f16x3: W is [batch][K][N] fp32 with arbitrary element strides.  Writes
- * planes [batch][2][N][K] fp16 = hi, lo of (W^T * s) and amax_scale[0] = max |W|, amax_scale[1] = s (pass
- * amax_scale + 1 as b_scale). */
+ * planes [batch][2][N*K] fp16 = hi, lo of (W^T * s) and amax_scale[0] = max |W|, amax_scale[1] = s (pass
+ * amax_scale + 1 as b_scale).  Element order inside a plane: K > 256: row-major [N][K] (k contiguous); K <= 256
+ * (K % 32 == 0: the shapes disgat_gemm_f16x3 runs on its A-stationary kernel): fragment-major - the 16 x 32 block of
+ * (n / 16, k / 32) is stored contiguously in MFMA lane order (lane = 16 * (k % 32 / 8) + n % 16, 8 halfs per lane), so
+ * a wave's weight-fragment load is one contiguous KB.  The two launchers share this rule; planes are opaque to callers. */
 int disgat_split_f16(const float* W, int64_t stride_b, int64_t stride_k, int64_t stride_n, int K, int N, int batch,
                      uint16_t* planes, float* amax_scale, disgat_stream_t stream);
 
