@@ -20,15 +20,21 @@ NOTES = {
 }
 
 
+def newest(pattern):
+    """Files of the most recent run only (a re-run merges next to the older process ids' files)."""
+    fs = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return fs[-1:] if fs else []
+
+
 def one(path):
-    fs = glob.glob(os.path.join(path, "*", "*_kernel_stats.csv"))
+    fs = newest(os.path.join(path, "*", "*_kernel_stats.csv"))
     return list(csv.DictReader(open(fs[0]))) if fs else []
 
 
 def counters(path):
     """kernel -> counter -> list of per-dispatch values"""
     out = {}
-    for f in glob.glob(os.path.join(path, "*", "*_counter_collection.csv")):
+    for f in newest(os.path.join(path, "*", "*_counter_collection.csv")):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].split("(")[0]
             out.setdefault(k, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
@@ -41,7 +47,7 @@ def main(src, dst):
         rows = one(os.path.join(src, tag))
         if not rows:
             continue
-        for f in glob.glob(os.path.join(src, tag, "*", "*_kernel_stats.csv")):
+        for f in newest(os.path.join(src, tag, "*", "*_kernel_stats.csv")):
             shutil.copy(f, os.path.join(dst, f"{tag}_kernel_stats.csv"))
         with open(os.path.join(dst, f"{tag}_summary.md"), "w") as out:
             P = lambda *a: print(*a, file=out)      # noqa: E731
