@@ -448,6 +448,9 @@ def main():
         local = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # the benchmark graphs reference 71-92 % of all nodes from every rank and the SSL passes score uniformly random
+        # pairs: the all-gather is the exchange they take anyway, so the halo planner (parallel.HaloPlan) is not even built
+        os.environ.setdefault("DISGAT_EXCHANGE", "allgather")
         if not rehearsal and torch.cuda.device_count() < world:
             raise SystemExit(f"--gpus {world} needs {world} visible GPUs (found {torch.cuda.device_count()}); "
                              "DISGAT_BENCH_REHEARSAL=1 rehearses the N-rank path on one GPU over gloo")
