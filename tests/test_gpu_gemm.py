@@ -1,6 +1,5 @@
 """The split-precision MFMA GEMMs (f16x3: two fp16 planes, 3 products - the default; split6: three bf16 planes, 6
 products) against float64, with hipBLASLt's fp32 GEMM as the accuracy yardstick."""
-import numpy as np
 import pytest
 import torch
 

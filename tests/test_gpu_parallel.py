@@ -29,7 +29,7 @@ def _worker(rank, world, port, q, golden_dir):
         os.environ["MASTER_PORT"] = str(port)
         dist.init_process_group("gloo", rank=rank, world_size=world)
         dev = torch.device("cuda:0")
-        from edgedisentangle_ssl_amd import parallel, pretrainer
+        from edgedisentangle_ssl_amd import parallel
         from edgedisentangle_ssl_amd.graph import CSRGraph
         from test_gpu_parity import build
         from test_gpu_backward import _trainers
