@@ -58,6 +58,10 @@
  *   3  e = sum_f a[h][f]*lrelu_0.01(P[row][h][f] + Q[col][h][f])
  *                                                      rowop = P, colop = Q [N][H*F_out], a [H*F_out]
  *      F_out must equal QN*(64/H)*4 with QN in {1,2,4,8} (host pads with zero columns).
+ *   4  (not a reference flag value) att 2 as layers.py:362-365 writes it, for inputs wider than att 2's 512-column
+ *      register tile: e = <h[row][h][:], h[col][h][:]>, h = x W per head - rowop = colop = h [N][H*F_out] in the
+ *      layout and padding of att 3, a = NULL, no nonlinearity.  Accepted by disgat_edge_fwd and disgat_aux_score;
+ *      disgat_seg_grad_att3 with a == NULL is its score backward.
  */
 #ifndef DISGAT_HIP_H
 #define DISGAT_HIP_H
