@@ -10,8 +10,10 @@ from . import _lib
 from .graph import CSRGraph
 
 # max edges per work item, by attention type: bounds the tail on power-law rows while keeping
-# the partial-record traffic (H*F_in floats per chunk) small next to the chunk's gather bytes.
-CHUNK = {1: 256, 2: 256, 3: 128, 4: 128}
+# the partial-record traffic (H*F_in floats per chunk) small next to the chunk's gather bytes.  att 3: 512 (round 1: 128;
+# same-box T_fwd at C4 with 64 / 128 / 256 / 512 / 1024 / 4096: 96.7 / 95.4 / 95.1 / 94.9 and 102.2 / 101.6 / 101.5 / 101.9 ms
+# on a slower box - the hub rows' slices start first, so coarser slices cost no tail and save partial records).
+CHUNK = {1: 256, 2: 256, 3: 512, 4: 512}
 
 
 # bench.py sets PROFILE to a list: every launch is then bracketed by HIP events recorded on the
