@@ -30,6 +30,11 @@ struct AuxArgs {
   uint32_t* sign;   // att 3, optional: [M][64] sign words for the backward pass (disgat_common.h)
 };
 
+// 64-pair batches one wave walks (its `a` vector and a row operand spanning batches are loaded once): same-box T_iter
+// at C4 with 1 / 2 / 4 / 8: 6363 / 6370 / 6397 / 6400 GB/s
+#ifndef AUX3_BATCHES
+#define AUX3_BATCHES 4
+#endif
 // att 3: lane = (head, g) exactly as in edge_fwd_kernel<3,...>.  DOT = att 4 (att 2 over the per-head projected
 // operands, layers.py:362-365): e = <P[row][h][:], Q[col][h][:]>, same lane map, no `a`, no nonlinearity.
 template <int HL, int QN, bool SIGN, bool DOT = false>
@@ -38,14 +43,13 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void aux_att3_kernel(const AuxArgs
   constexpr int G = 1 << GL;
   constexpr int FQ = QN * G * 4;
   const int lane = threadIdx.x & 63;
-  const int64_t m0 = ((int64_t)blockIdx.x * DISGAT_WAVES_PER_BLOCK + (threadIdx.x >> 6)) * 64;
-  if (m0 >= A.M) return;
-  const int cnt = (int)min((int64_t)64, A.M - m0);
+  const int64_t mw = ((int64_t)blockIdx.x * DISGAT_WAVES_PER_BLOCK + (threadIdx.x >> 6)) * (64 * AUX3_BATCHES);
+  if (mw >= A.M) return;
   const int myh = lane >> GL;
   const bool active = (myh >= A.h_lo) && (myh < A.h_hi);
   const int qoff = myh * FQ + (lane & (G - 1)) * 4;
-  const int rv = (lane < cnt) ? (int)A.pr[m0 + lane] : 0;
-  const int cv = (lane < cnt) ? (int)A.pc[m0 + lane] : 0;
+  int64_t m0 = mw;                 // the wave's current batch of 64 pairs (AUX3_BATCHES consecutive batches per wave:
+  int cnt = 0, rv = 0, cv = 0;     // `a` and a row operand that spans batches are loaded once)
 
   f32x4 a_r[QN], p_r[QN], qA[QN], qB[QN];
 #pragma unroll
@@ -102,20 +106,27 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void aux_att3_kernel(const AuxArgs
     for (int t = 0; t < KEEP; ++t) keep[t] = (mine && slot == t) ? acc : keep[t];
   };
 
-  load_q(qA, __builtin_amdgcn_readlane(cv, 0));
-  int i = 0;
-  for (; i + 1 < cnt; i += 2) {
-    load_q(qB, __builtin_amdgcn_readlane(cv, i + 1));
-    compute(qA, i);
-    if (i + 2 < cnt) load_q(qA, __builtin_amdgcn_readlane(cv, i + 2));
-    compute(qB, i + 1);
-  }
-  if (i < cnt) compute(qA, i);
-  if (active) {
-    float* op = A.out + (int64_t)myh * A.M + m0 + g;
+  for (int b = 0; b < AUX3_BATCHES; ++b) {
+    m0 = mw + (int64_t)b * 64;
+    if (m0 >= A.M) break;
+    cnt = (int)min((int64_t)64, A.M - m0);
+    rv = (lane < cnt) ? (int)A.pr[m0 + lane] : 0;
+    cv = (lane < cnt) ? (int)A.pc[m0 + lane] : 0;
+    load_q(qA, __builtin_amdgcn_readlane(cv, 0));
+    int i = 0;
+    for (; i + 1 < cnt; i += 2) {
+      load_q(qB, __builtin_amdgcn_readlane(cv, i + 1));
+      compute(qA, i);
+      if (i + 2 < cnt) load_q(qA, __builtin_amdgcn_readlane(cv, i + 2));
+      compute(qB, i + 1);
+    }
+    if (i < cnt) compute(qA, i);
+    if (active) {
+      float* op = A.out + (int64_t)myh * A.M + m0 + g;
 #pragma unroll
-    for (int t = 0; t < KEEP; ++t)
-      if (t * G + g < cnt) op[t * G] = keep[t];
+      for (int t = 0; t < KEEP; ++t)
+        if (t * G + g < cnt) op[t * G] = keep[t];
+    }
   }
 }
 
@@ -334,7 +345,8 @@ extern "C" int disgat_aux_score(int att, const int64_t* pair_rows, const int64_t
   AuxArgs A{pair_rows, pair_cols, M, N, F_in, h_lo, h_hi, x, ldx, rowop, ld_row, colop, ld_col, a, out,
             att == 3 ? sign_bits : nullptr};
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const int64_t waves = (M + 63) / 64;
+  const int64_t per_wave = (att == 3 || att == 4) ? 64 * AUX3_BATCHES : 64;
+  const int64_t waves = (M + per_wave - 1) / per_wave;
   const int64_t grid64 = (waves + DISGAT_WAVES_PER_BLOCK - 1) / DISGAT_WAVES_PER_BLOCK;
   DISGAT_REQUIRE(grid64 < (int64_t)1 << 31, "aux_score: M too large for one launch");
   const int grid = (int)grid64;
