@@ -5,7 +5,9 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef DISGAT_WAVES_PER_BLOCK
 #define DISGAT_WAVES_PER_BLOCK 4
+#endif
 #define DISGAT_BLOCK (64 * DISGAT_WAVES_PER_BLOCK)
 
 namespace disgat {
