@@ -74,13 +74,18 @@ def run(argv=None, log=print):
     # one process per GPU (torch.distributed.run sets RANK / WORLD_SIZE / LOCAL_RANK): the graph is partitioned by
     # row ranges on load, every rank keeps its own rows of the features, labels stay global
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
-    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) if world > 1 else torch.cuda.current_device())
+    backend = os.environ.get("DISGAT_DIST_BACKEND", "nccl")      # "gloo": several ranks sharing one GPU (tests / rehearsal)
+    local = 0 if backend == "gloo" else int(os.environ.get("LOCAL_RANK", "0"))
+    dev = torch.device("cuda", local if world > 1 else torch.cuda.current_device())
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(dev)
         if not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group("nccl", device_id=dev)
+            if backend == "gloo":
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=dev)
     if args.fixture:
         adj, features, labels = data_load.load_fixture(args.fixture)
         if features is None:

@@ -219,3 +219,36 @@ def _train_worker(rank, world, port, q, golden_dir):
 
 def test_sharded_train_steps_two_ranks_one_gpu(golden_dir):
     _run_ranks(_train_worker, 2, (golden_dir,))
+
+
+def _main_worker(rank, world, port, q, golden_dir):
+    """edgedisentangle_ssl_amd.main.run as one of two ranks (torch.distributed.run's environment, gloo on one GPU):
+    partition on load / shard the fixture, static feature exchange, sharded CLS + SSL train_steps, logs."""
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                          LOCAL_RANK=str(rank), DISGAT_DIST_BACKEND="gloo")
+        import math
+        from edgedisentangle_ssl_amd import main
+        argv = ["--model=DISGAT", "--sparse", "--dataset", "chameleon", "--fixture", os.path.join(golden_dir, "data_chameleon.npz"),
+                "--gnn_type", "AT", "--att", "3", "--nhead", "4", "--nhid", "32", "--epochs", "4", "--steps", "2",
+                "--downstream", "CLS", "--down_weight", "1.0", "--finetune", "--pretrain", "SupEdge", "DisEdge", "DifHead",
+                "--pre_weight", "1", "1", "1", "--pre_edge", "1", "1", "1", "--dropout", "0.1", "--seed", "4", "--quiet"]
+        hist = main.run(argv)
+        assert len(hist) == 4
+        for h in hist:
+            for k in ("loss_train", "loss_heads_sup", "loss_head_disen", "loss_head_diversity"):
+                assert math.isfinite(h[k]), (k, h)
+        vals = torch.tensor([hist[-1]["loss_train"], hist[-1]["loss_head_diversity"], hist[0]["test_acc_test"]], dtype=torch.float64)
+        both = [torch.empty_like(vals) for _ in range(world)]
+        dist.all_gather(both, vals)
+        assert all(torch.allclose(b, both[0], rtol=1e-6) for b in both), both     # global losses: same number on every rank
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc()))
+
+
+def test_main_run_two_ranks_one_gpu(golden_dir):
+    _run_ranks(_main_worker, 2, (golden_dir,))
