@@ -7,7 +7,7 @@ travels to the GPU box); the product never imports this.  The reference's .py
 files are imported in place with an in-memory `ipdb` stub; nothing
 is copied out of them - fixtures hold inputs-by-seed and expected OUTPUTS only.
 
-Usage:  python oracle/gen_golden.py [--only tiny|prims|real]
+Usage:  python oracle/gen_golden.py [--only tiny|prims|traj|real]
 """
 import argparse
 import os
@@ -239,6 +239,54 @@ def gen_tiny():
     print("tiny_ref_sampler", {k: v.shape for k, v in out.items()})
 
 
+def gen_trajectory():
+    """Several optimiser steps of the reference's own trainers (pretrainer.py:709-763, 578-641, 810-847 with
+    trainer.py:58-60's per-module Adam) on the tiny graph with injected pair lists, dropout 0: the parameters afterwards
+    pin backward + Adam (lr, weight decay, one optimiser per sub-module, the encoder stepped by every trainer) end to end."""
+    idx, vals, n = ic.tiny_graph()
+    adj = sparse_adj(idx, vals, n)
+    x = ic.features(21, n, 16)
+    labels = torch.from_numpy(np.random.Generator(np.random.PCG64(3)).integers(0, 3, n))
+    ci = ic.coalesced_index_set(idx, n)
+    pos, homo, het = ic.edge_sets(ci, labels, n)
+    sup_idx, sup_lab = ic.sample_pairs(31, n, pos, "sup")
+    ho_idx, ho_lab = ic.sample_pairs(32, n, homo, "homo")
+    he_idx, he_lab = ic.sample_pairs(33, n, het, "het")
+    for gnn, att in (("AT", 3), ("SAGE", 1), ("GCN", 2), ("SAGE", 3)):
+        seed = 100 + att
+        a = ref_args(gnn, att, 4, 16, 16)
+        a.lr, a.weight_decay = 0.01, 5e-4
+        enc = ic.load_params(ref_models.DISGAT(a, nfeat=16, nhid=16, nclass=16, nheads=4, dropout=0.0), seed)
+        trs = []
+        for k, cls in enumerate((ref_pre.SupEdgeTrainer, ref_pre.GeneratedEdgeTrainer, ref_pre.DifHeadTrainer)):
+            tr = cls(a, enc, [1.0, 0.5, 2.0][k])
+            ic.load_params(tr.fuse1, seed + 1 + 10 * k)
+            ic.load_params(tr.fuse2, seed + 2 + 10 * k)
+            trs.append(tr)
+        ic.load_params(trs[2].classifier1, seed + 4)
+        ic.load_params(trs[2].classifier2, seed + 5)
+        inject_sampler(trs[0], (sup_lab, [sup_idx]))
+        trs[1].dis_adjs = [None, None]
+        inject_sampler(trs[1], ([ho_lab, he_lab], [ho_idx, he_idx]))
+        out, logs = {}, []
+        for _ in range(3):                                        # main.py:335-352: every SSL trainer once per epoch
+            logs.append(trs[0].train_step((x, adj), None)["loss_heads_sup"])
+            logs.append(trs[1].train_step((x, adj))["loss_head_disen"])
+            logs.append(trs[2].train_step((x, adj))["loss_head_diversity"])
+        out["losses"] = np.asarray(logs, dtype=np.float32)
+        for k, v in enc.state_dict().items():
+            out["enc." + k] = np32(v)
+        for t, tr in enumerate(trs):
+            for nm in ("fuse1", "fuse2"):
+                for k, v in getattr(tr, nm).state_dict().items():
+                    out[f"t{t}.{nm}.{k}"] = np32(v)
+        for nm in ("classifier1", "classifier2"):
+            for k, v in getattr(trs[2], nm).state_dict().items():
+                out[f"t2.{nm}.{k}"] = np32(v)
+        np.savez_compressed(os.path.join(GOLD, f"tiny_traj_{gnn}_att{att}.npz"), **out)
+        print("trajectory", gnn, att, "losses", np.round(out["losses"], 5).tolist())
+
+
 # --------------------------------------------------------------------------- real graphs
 def processed_index_set(a):
     """Index set of data_load.load_data's processed adjacency (data_load.py:66-81):
@@ -341,6 +389,8 @@ if __name__ == "__main__":
             gen_prims()
         if o.only in (None, "tiny"):
             gen_tiny()
+        if o.only in (None, "traj"):
+            gen_trajectory()
         if o.only in (None, "real"):
             gen_real(o.skip_existing)
         os.chdir(REPO)
