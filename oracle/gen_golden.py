@@ -254,9 +254,16 @@ def gen_trajectory():
     he_idx, he_lab = ic.sample_pairs(33, n, het, "het")
     for gnn, att in (("AT", 3), ("SAGE", 1), ("GCN", 2), ("SAGE", 3)):
         seed = 100 + att
-        a = ref_args(gnn, att, 4, 16, 16)
+        a = ref_args(gnn, att, 4, 16, 16, extra=("--reg",) if att != 1 else ())
         a.lr, a.weight_decay = 0.01, 5e-4
         enc = ic.load_params(ref_models.DISGAT(a, nfeat=16, nhid=16, nclass=16, nheads=4, dropout=0.0), seed)
+        import random
+        import trainer as ref_trainer
+        random.seed(5)                                            # utils.py:134,151: the split shuffles with `random`
+        ct = ref_trainer.ClsTrainer(a, enc, labels, 1.5)
+        ic.load_params(ct.fuse1, seed + 41)
+        ic.load_params(ct.fuse2, seed + 42)
+        ic.load_params(ct.classifier, seed + 43)
         trs = []
         for k, cls in enumerate((ref_pre.SupEdgeTrainer, ref_pre.GeneratedEdgeTrainer, ref_pre.DifHeadTrainer)):
             tr = cls(a, enc, [1.0, 0.5, 2.0][k])
@@ -268,11 +275,21 @@ def gen_trajectory():
         inject_sampler(trs[0], (sup_lab, [sup_idx]))
         trs[1].dis_adjs = [None, None]
         inject_sampler(trs[1], ([ho_lab, he_lab], [ho_idx, he_idx]))
-        out, logs = {}, []
-        for _ in range(3):                                        # main.py:335-352: every SSL trainer once per epoch
+        out, logs, cls_logs = {}, [], []
+        for ep in range(3):                                       # main.py:335-352: every SSL trainer once per epoch
             logs.append(trs[0].train_step((x, adj), None)["loss_heads_sup"])
             logs.append(trs[1].train_step((x, adj))["loss_head_disen"])
             logs.append(trs[2].train_step((x, adj))["loss_head_diversity"])
+            lg = ct.train_step((x, adj), labels, ep)              # main.py:354: the node classifier after the SSL steps
+            cls_logs.append([lg[k] for k in ("loss_train", "acc_train", "loss_reg", "loss_val", "acc_val")])
+        lt = ct.test((x, adj), labels)
+        out["cls_test"] = np.asarray([lt["loss_test"], lt["acc_test"], lt["roc_test"], lt["macroF_test"]], dtype=np.float64)
+        out["cls_logs"] = np.asarray(cls_logs, dtype=np.float64)
+        for nm, idxs in (("idx_train", ct.idx_train), ("idx_val", ct.idx_val), ("idx_test", ct.idx_test)):
+            out[nm] = idxs.numpy().astype(np.int64)
+        for nm in ("fuse1", "fuse2", "classifier"):
+            for k, v in getattr(ct, nm).state_dict().items():
+                out[f"cls.{nm}.{k}"] = np32(v)
         out["losses"] = np.asarray(logs, dtype=np.float32)
         for k, v in enc.state_dict().items():
             out["enc." + k] = np32(v)

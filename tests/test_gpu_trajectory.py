@@ -1,5 +1,6 @@
 """GPU parity of whole optimiser steps: three epochs of SupEdge -> DisEdge -> DifHead train steps (main.py:335-352's order)
-on the tiny graph with the reference's own pair lists injected, against the parameters the unmodified reference ends with
+followed by the node classifier's step (trainer.py:178-223, with and without the fusers' L1 term) on the tiny graph with
+the reference's own pair lists injected, against the parameters the unmodified reference ends with
 (tests/golden/tiny_traj_*.npz, written by oracle/gen_golden.py --only traj).  Pins backward + the fused Adam
 (trainer.py:58-60: one optimiser per sub-module, lr / weight decay from args, the encoder stepped by every trainer with
 that trainer's own moment estimates) and the loss weights (pretrainer.py:750-756) end to end."""
@@ -19,7 +20,9 @@ PTOL = 5e-5          # parameters after 9 Adam steps of lr 0.01: the reference's
 
 @pytest.mark.parametrize("gnn,att", [("AT", 3), ("SAGE", 1), ("GCN", 2), ("SAGE", 3)])
 def test_parameters_after_three_epochs_match_the_reference(golden_dir, dev, gnn, att):
-    from edgedisentangle_ssl_amd import pretrainer
+    import random
+    from edgedisentangle_ssl_amd import pretrainer, utils
+    from edgedisentangle_ssl_amd.trainer import ClsTrainer
     g = np.load(os.path.join(golden_dir, f"tiny_traj_{gnn}_att{att}.npz"))
     x, adj, n, _ = tiny_inputs(dev)
     idx, _, _ = ic.tiny_graph()
@@ -32,6 +35,15 @@ def test_parameters_after_three_epochs_match_the_reference(golden_dir, dev, gnn,
     seed = 100 + att
     a, enc, _ = build(gnn, att, 4, 16, 16, seed, dev)
     a.lr, a.weight_decay, a.dis_type = 0.01, 5e-4, 1
+    a.reg, a.reg_weight, a.node_sup_ratio, a.fuse = att != 1, 0.01, 0.25, "last"
+    random.seed(5)                      # utils.py:118-151: the class-wise split shuffles with python's `random`
+    ct = ClsTrainer(a, enc, labels.to(dev), 1.5)
+    for nm in ("idx_train", "idx_val", "idx_test"):
+        np.testing.assert_array_equal(getattr(ct, nm).cpu().numpy(), g[nm])
+    ic.load_params(ct.fuse1, seed + 41)
+    ic.load_params(ct.fuse2, seed + 42)
+    ic.load_params(ct.classifier, seed + 43)
+    ct.full_metrics = True
     trs = []
     for k, cls in enumerate((pretrainer.SupEdgeTrainer, pretrainer.GeneratedEdgeTrainer, pretrainer.DifHeadTrainer)):
         tr = cls(a, enc, WEIGHTS[k])
@@ -47,11 +59,18 @@ def test_parameters_after_three_epochs_match_the_reference(golden_dir, dev, gnn,
     trs[0].sample_train = lambda gt: (sup[1], [sup[0]])
     trs[1].sample_train = lambda: ([ho[1], he[1]], [ho[0], he[0]])
     data = (x, adj)
-    logs = []
-    for _ in range(3):
+    logs, cls_logs = [], []
+    for ep in range(3):
         logs.append(trs[0].train_step(data)["loss_heads_sup"])
         logs.append(trs[1].train_step(data)["loss_head_disen"])
         logs.append(trs[2].train_step(data)["loss_head_diversity"])
+        lg = utils.resolve_logs(ct.train_step(data, labels.to(dev), ep))
+        cls_logs.append([float(lg[k]) for k in ("loss_train", "acc_train", "loss_reg", "loss_val", "acc_val")])
+    np.testing.assert_allclose(np.asarray(cls_logs), g["cls_logs"], rtol=2e-4, atol=2e-5)
+    lt = ct.test(data, labels.to(dev))
+    # loss / accuracy / sklearn ROC-AUC and macro-F1 of the test split (trainer.py:296-318)
+    np.testing.assert_allclose([lt["loss_test"], lt["acc_test"], lt["roc_test"], lt["macroF_test"]], g["cls_test"],
+                               rtol=2e-4, atol=2e-5)
     got = torch.stack([torch.as_tensor(v).float().reshape(()) for v in logs]).cpu().numpy()
     np.testing.assert_allclose(got, g["losses"], rtol=2e-4, atol=2e-5)      # the reference rounds its logs to 5 decimals
     checked = 0
@@ -67,4 +86,8 @@ def test_parameters_after_three_epochs_match_the_reference(golden_dir, dev, gnn,
         for k, p in getattr(trs[2], nm).state_dict().items():
             close(p, g[f"t2.{nm}.{k}"], tol=PTOL, what=f"t2.{nm}.{k}")
             checked += 1
-    assert checked == len(g.files) - 1
+    for nm in ("fuse1", "fuse2", "classifier"):
+        for k, p in getattr(ct, nm).state_dict().items():
+            close(p, g[f"cls.{nm}.{k}"], tol=PTOL, what=f"cls.{nm}.{k}")
+            checked += 1
+    assert checked == len(g.files) - 6          # losses, cls_logs, cls_test and the three index sets

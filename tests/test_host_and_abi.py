@@ -249,3 +249,18 @@ def test_conformT_restricts_disedge_groups_to_the_labelled_split():
     both = known[g.row] & known[g.col.long()]
     assert homo_c.numel() == int((same & both).sum()) and het_c.numel() == int((~same & both).sum())
     assert tr.n_pos_global == [homo_c.numel(), het_c.numel()]
+
+
+def test_split_reproduces_the_reference_index_sets(golden_dir):
+    """utils.split (utils.py:118-161 of the reference) draws with python's `random`: under the same seed the train / val /
+    test node sets equal the ones the reference produced when the trajectory goldens were recorded."""
+    import random
+    from edgedisentangle_ssl_amd.utils import split
+    g = np.load(os.path.join(golden_dir, "tiny_traj_AT_att3.npz"))
+    labels = torch.from_numpy(np.random.Generator(np.random.PCG64(3)).integers(0, 3, 64))
+    random.seed(5)
+    tr, va, te, mat = split(labels, train_ratio=0.25)
+    np.testing.assert_array_equal(tr.numpy(), g["idx_train"])
+    np.testing.assert_array_equal(va.numpy(), g["idx_val"])
+    np.testing.assert_array_equal(te.numpy(), g["idx_test"])
+    assert int(mat[:, 0].sum()) == len(tr) and int(mat[:, 2].sum()) == len(te)
