@@ -7,7 +7,7 @@ travels to the GPU box); the product never imports this.  The reference's .py
 files are imported in place with an in-memory `ipdb` stub; nothing
 is copied out of them - fixtures hold inputs-by-seed and expected OUTPUTS only.
 
-Usage:  python oracle/gen_golden.py [--only tiny|prims|traj|real]
+Usage:  python oracle/gen_golden.py [--only tiny|prims|traj|labels|real]
 """
 import argparse
 import os
@@ -304,6 +304,28 @@ def gen_trajectory():
         print("trajectory", gnn, att, "losses", np.round(out["losses"], 5).tolist())
 
 
+def gen_labels():
+    """GeneratedEdgeTrainer.get_label_all (pretrainer.py:386-513) on the tiny graph: the homo / hetero edge groups with every
+    node label known (:448-456) and under --conformT (:465-498, train + val nodes of utils.split only), as flat row*N+col ids."""
+    import random
+    idx, vals, n = ic.tiny_graph()
+    adj = sparse_adj(idx, vals, n)
+    x = ic.features(21, n, 16)
+    labels = torch.from_numpy(np.random.Generator(np.random.PCG64(3)).integers(0, 3, n))
+    out = {}
+    for tag, extra in (("all", ()), ("conformT", ("--conformT",))):
+        a = ref_args("AT", 3, 4, 16, 16, extra=extra)
+        enc = ref_models.DISGAT(a, nfeat=16, nhid=16, nclass=16, nheads=4, dropout=0.0)
+        tr = ref_pre.GeneratedEdgeTrainer(a, enc, 1.0)
+        random.seed(11)
+        groups = tr.get_label_all(x, adj, labels, load=False)
+        for nm, grp in zip(("homo", "hetero"), groups):
+            nz = grp.nonzero()
+            out[f"{tag}.{nm}"] = (nz[:, 0] * n + nz[:, 1]).numpy().astype(np.int64)
+    np.savez_compressed(os.path.join(GOLD, "tiny_edge_groups.npz"), **out)
+    print("edge groups", {k: len(v) for k, v in out.items()})
+
+
 # --------------------------------------------------------------------------- real graphs
 def processed_index_set(a):
     """Index set of data_load.load_data's processed adjacency (data_load.py:66-81):
@@ -408,6 +430,8 @@ if __name__ == "__main__":
             gen_tiny()
         if o.only in (None, "traj"):
             gen_trajectory()
+        if o.only in (None, "labels"):
+            gen_labels()
         if o.only in (None, "real"):
             gen_real(o.skip_existing)
         os.chdir(REPO)

@@ -264,3 +264,25 @@ def test_split_reproduces_the_reference_index_sets(golden_dir):
     np.testing.assert_array_equal(va.numpy(), g["idx_val"])
     np.testing.assert_array_equal(te.numpy(), g["idx_test"])
     assert int(mat[:, 0].sum()) == len(tr) and int(mat[:, 2].sum()) == len(te)
+
+
+@pytest.mark.parametrize("conform", [False, True])
+def test_edge_groups_equal_the_reference_label_builder(golden_dir, conform):
+    """GeneratedEdgeTrainer.get_label_all against the groups the reference built from its dense N x N masks
+    (pretrainer.py:448-456 and, under --conformT, :465-498) on the tiny graph: same flat row*N+col id sets."""
+    import random
+    from types import SimpleNamespace
+    from edgedisentangle_ssl_amd import pretrainer
+    from edgedisentangle_ssl_amd.graph import CSRGraph
+    gold = np.load(os.path.join(golden_dir, "tiny_edge_groups.npz"))
+    idx, _vals, n = ic.tiny_graph()
+    g = CSRGraph.from_index(idx, n)
+    labels = torch.from_numpy(np.random.Generator(np.random.PCG64(3)).integers(0, 3, n))
+    tr = pretrainer.GeneratedEdgeTrainer.__new__(pretrainer.GeneratedEdgeTrainer)
+    tr.dis_type = 1
+    tr.args = SimpleNamespace(conformT=conform, node_sup_ratio=0.25)
+    random.seed(11)
+    homo, het = tr.get_label_all(None, g, labels)
+    tag = "conformT" if conform else "all"
+    np.testing.assert_array_equal(homo.numpy(), gold[f"{tag}.homo"])
+    np.testing.assert_array_equal(het.numpy(), gold[f"{tag}.hetero"])
