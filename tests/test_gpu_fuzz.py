@@ -1,4 +1,4 @@
-"""A slice of tools/fuzz_parity.py in the GPU suite: random graphs / heads / widths / attention and
+"""A slice of tests/fuzz_parity.py in the GPU suite: random graphs / heads / widths / attention and
 aggregation types / aux lists / head ranges / chunk sizes, forward + backward vs the float64 oracle."""
 import os
 import sys
@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize("seed", [10, 11])
