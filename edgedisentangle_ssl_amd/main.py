@@ -51,9 +51,7 @@ def run(argv=None, log=print):
     if args.model != "DISGAT":
         raise SystemExit("only --model=DISGAT is implemented by this package (SURVEY 2: other encoders out of scope)")
     for flag, why in (("batch", "sub-graph mini-batching (dataset.py) is outside the DISGAT hot path (SURVEY 2 row 22)"),
-                      ("hnn", "the heterogeneous-network encoders are outside the DISGAT hot path (SURVEY 2 row 17)"),
-                      ("case", "the --case heat-map study is reporting only (SURVEY 2 row 23); "
-                               "Trainer.analyze_disentangle returns the same grids")):
+                      ("hnn", "the heterogeneous-network encoders are outside the DISGAT hot path (SURVEY 2 row 17)")):
         if getattr(args, flag):
             raise SystemExit("--{}: {}".format(flag, why))
     if not torch.cuda.is_available() or args.no_cuda:
@@ -139,6 +137,13 @@ def run(argv=None, log=print):
         if epoch % 40 == 0:
             for i, tr in enumerate(down):
                 log_ep.update({"test_" + k: v for k, v in tr.test([features, adj], labels, epoch).items()})
+            if args.case and down:
+                # main.py:289-301: head-to-head score correlation of the two layers (the reference also draws the grids
+                # into tensorboard; Trainer.analyze_disentangle returns them)
+                if world > 1:
+                    raise SystemExit("--case: the disentanglement study runs on one process")
+                dist, _at, _feat = down[-1].analyze_disentangle(features, adj)
+                log_ep.update({"att_correlation_layer1": dist[0], "att_correlation_layer2": dist[1]})
         if args.finetune:
             for _ in range(args.steps):
                 for tr in down:

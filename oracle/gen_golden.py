@@ -276,12 +276,12 @@ def gen_trajectory():
         trs[1].dis_adjs = [None, None]
         inject_sampler(trs[1], ([ho_lab, he_lab], [ho_idx, he_idx]))
         out, logs, cls_logs = {}, [], []
-        for ep in range(3):                                       # main.py:335-352: every SSL trainer once per epoch
-            logs.append(trs[0].train_step((x, adj), None)["loss_heads_sup"])
+        for ep in range(3):
+            lg = ct.train_step((x, adj), labels, ep)              # main.py:313-329: the fine-tuning step comes first,
+            cls_logs.append([lg[k] for k in ("loss_train", "acc_train", "loss_reg", "loss_val", "acc_val")])
+            logs.append(trs[0].train_step((x, adj), None)["loss_heads_sup"])      # main.py:335-352: then every SSL trainer
             logs.append(trs[1].train_step((x, adj))["loss_head_disen"])
             logs.append(trs[2].train_step((x, adj))["loss_head_diversity"])
-            lg = ct.train_step((x, adj), labels, ep)              # main.py:354: the node classifier after the SSL steps
-            cls_logs.append([lg[k] for k in ("loss_train", "acc_train", "loss_reg", "loss_val", "acc_val")])
         lt = ct.test((x, adj), labels)
         out["cls_test"] = np.asarray([lt["loss_test"], lt["acc_test"], lt["roc_test"], lt["macroF_test"]], dtype=np.float64)
         out["cls_logs"] = np.asarray(cls_logs, dtype=np.float64)

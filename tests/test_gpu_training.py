@@ -16,8 +16,12 @@ def test_main_flow_trains(golden_dir, gnn, att):
             "--gnn_type", gnn, "--att", str(att), "--nhead", "4", "--nhid", "32", "--epochs", "8", "--steps", "2",
             "--downstream", "CLS", "--down_weight", "1.0", "--finetune", "--pretrain", "SupEdge", "DisEdge", "DifHead",
             "--pre_weight", "1", "1", "1", "--pre_edge", "1", "1", "1", "--dropout", "0.1", "--seed", "4", "--quiet"]
+    if gnn == "AT":
+        argv.append("--case")            # main.py:289-301: the disentanglement study every 40th epoch
     hist = main.run(argv)
     assert len(hist) == 8
+    if gnn == "AT":
+        assert 0.0 < hist[0]["att_correlation_layer1"] <= 1.0 + 1e-6 and 0.0 < hist[0]["att_correlation_layer2"] <= 1.0 + 1e-6
     for h in hist:
         for k in ("loss_train", "loss_heads_sup", "loss_head_disen", "loss_head_diversity"):
             assert math.isfinite(h[k]), (k, h)

@@ -1,5 +1,5 @@
-"""GPU parity of whole optimiser steps: three epochs of SupEdge -> DisEdge -> DifHead train steps (main.py:335-352's order)
-followed by the node classifier's step (trainer.py:178-223, with and without the fusers' L1 term) on the tiny graph with
+"""GPU parity of whole optimiser steps: three epochs of the node classifier's step (trainer.py:178-223, with and without the
+fusers' L1 term) followed by SupEdge -> DisEdge -> DifHead train steps (main.py:313-352's order) on the tiny graph with
 the reference's own pair lists injected, against the parameters the unmodified reference ends with
 (tests/golden/tiny_traj_*.npz, written by oracle/gen_golden.py --only traj).  Pins backward + the fused Adam
 (trainer.py:58-60: one optimiser per sub-module, lr / weight decay from args, the encoder stepped by every trainer with
@@ -15,7 +15,11 @@ from test_gpu_parity import build, close, dev, tiny_inputs  # noqa: F401
 
 pytestmark = pytest.mark.gpu
 WEIGHTS = [1.0, 0.5, 2.0]
-PTOL = 5e-5          # parameters after 9 Adam steps of lr 0.01: the reference's fp32 run itself is reproducible to ~1e-6
+# Parameters after 12 Adam steps of lr 0.01.  Adam divides by sqrt(v): where a gradient is tiny (the att-1 score weights
+# behind the softmax of a sigmoid) its fp32 rounding noise - the reference's as much as ours - moves the parameter by up to
+# lr * (relative gradient error) per step, ~1.5e-4 here; everything else agrees to ~1e-6.  A wrong step order, shared
+# moments, a missing optimiser or a wrong lr shows up at 1e-3..1e-2.
+PTOL = 4e-4
 
 
 @pytest.mark.parametrize("gnn,att", [("AT", 3), ("SAGE", 1), ("GCN", 2), ("SAGE", 3)])
@@ -61,11 +65,11 @@ def test_parameters_after_three_epochs_match_the_reference(golden_dir, dev, gnn,
     data = (x, adj)
     logs, cls_logs = [], []
     for ep in range(3):
+        lg = utils.resolve_logs(ct.train_step(data, labels.to(dev), ep))          # main.py:313-352: fine-tuning step, then SSL
+        cls_logs.append([float(lg[k]) for k in ("loss_train", "acc_train", "loss_reg", "loss_val", "acc_val")])
         logs.append(trs[0].train_step(data)["loss_heads_sup"])
         logs.append(trs[1].train_step(data)["loss_head_disen"])
         logs.append(trs[2].train_step(data)["loss_head_diversity"])
-        lg = utils.resolve_logs(ct.train_step(data, labels.to(dev), ep))
-        cls_logs.append([float(lg[k]) for k in ("loss_train", "acc_train", "loss_reg", "loss_val", "acc_val")])
     np.testing.assert_allclose(np.asarray(cls_logs), g["cls_logs"], rtol=2e-4, atol=2e-5)
     lt = ct.test(data, labels.to(dev))
     # loss / accuracy / sklearn ROC-AUC and macro-F1 of the test split (trainer.py:296-318)
