@@ -39,3 +39,27 @@ def test_bench_two_ranks_under_torchrun(scaling):
     assert out["value"] > 0 and out["ms_per_step"] > 0
     assert out["cpu_baseline"] is None or "value" in out["cpu_baseline"]
     assert out["roofline"]["bound"] == "hbm" and 0 < out["roofline"]["frac"] < 1
+
+
+def test_bench_one_gpu_json_contract():
+    """`python bench.py` (N = 1) on a small graph: ONE JSON line carrying every field of the driver's contract, the
+    roofline object measured with HIP events on the launch stream and the CPU baseline (the oracle, timed on a sample)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--nodes", "20000", "--edges", "400000",
+           "--feat", "64", "--no-secondary", "--cpu-nodes", "1024"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in out, key
+    assert out["n_gpus"] == 1 and out["steps"] == 2 and out["warmup"] == 1 and out["higher_is_better"] is True
+    assert out["vs_baseline"] is None and "workload" in out["config"] and "model" not in out["config"]
+    roof = out["roofline"]
+    assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+    cpu = out["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["value"] > 0 and cpu["cores"] >= 1 and cpu["sample"]
+    assert abs(out["value"] - out["config"]["nnz_total"] / (out["ms_per_step"] * 1e-3)) / out["value"] < 1e-3
