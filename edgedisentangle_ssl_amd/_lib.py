@@ -14,7 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libdisgat_hip.so")
-SOURCES = ["api_common.hip", "edge_fwd.hip", "aux_score.hip", "edge_bwd.hip", "gemm_split.hip", "optim.hip"]
+SOURCES = ["api_common.hip", "edge_fwd.hip", "aux_score.hip", "edge_bwd.hip", "gemm_split.hip", "gemm_planes.hip", "optim.hip"]
 ARCH = "gfx950"
 
 _lib = None
@@ -111,6 +111,15 @@ _SIGS = {
     "disgat_gemm_f16x3_tn": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _P, _c.c_int64, _c.c_int64, _P, _P, _P, _c.c_int, _c.c_int,
                                         _c.c_int, _c.c_int, _c.c_int, _P]),
     "disgat_split_f16": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _P, _P, _P]),
+    "disgat_split_f16_rm": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _P, _P, _P]),
+    "disgat_gemm_planes": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _P, _P, _P, _P, _P, _c.c_int64, _c.c_int64, _P,
+                                      _c.c_int64, _c.c_int64, _P, _P, _c.c_int64, _c.c_int64, _P, _c.c_int, _c.c_int,
+                                      _c.c_int, _c.c_int, _c.c_int, _c.c_float, _P]),
+    "disgat_split_planes": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _P, _P, _P, _c.c_int64,
+                                       _c.c_int64, _P]),
+    "disgat_planes_to_f32": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _P, _P, _c.c_int64,
+                                        _c.c_int64, _P]),
+    "disgat_debug_stamps": (_c.c_int, [_P, _c.c_int]),
     "disgat_amax": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _P, _P]),
     "disgat_act_bwd": (_c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int, _c.c_float, _P, _P]),
     "disgat_adam_multi": (_c.c_int, [_c.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _c.c_double, _c.c_double, _c.c_float, _P]),

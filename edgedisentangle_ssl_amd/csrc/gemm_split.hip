@@ -37,15 +37,12 @@
 // before the 96 MFMAs of the current one (two-tile-deep register prefetch, single LDS stage, 48 KB, 2
 // blocks/CU).  Block ids are remapped so that all N-tiles of one M-tile run on one XCD (A tile
 // served by that XCD's L2).  Epilogue fuses bias, an additive init matrix and ELU / leaky-ReLU.
-#include "disgat_common.h"
+#include "gemm_common.h"
 #include <type_traits>
 
 namespace disgat {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x4v __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 struct GemmArgs {
   const float* A;
@@ -269,8 +266,6 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs G) {
 // and accumulate in their own fp32 accumulator (folding the weight into lo would push lo into fp16's
 // subnormal range for all but the largest elements).  C = (acc_hh + 2^-11 acc_x) / (s_A s_B).
 // Measured error vs fp64: tests/test_gpu_gemm.py (yardstick hipBLASLt fp32).
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 struct GemmHArgs {
   const float* A;
@@ -288,29 +283,6 @@ struct GemmHArgs {
   float slope;
   int mt, nt;
 };
-
-// power-of-two scale that places amax in [2^13, 2^14); 1 for zero / non-finite input
-__device__ __forceinline__ float f16_scale(float amax) {
-  if (!(amax > 0.f) || !(amax < 3.0e38f)) return 1.0f;
-  int e;
-  (void)frexpf(amax, &e);                       // amax = m * 2^e, m in [0.5, 1)
-  e = max(-100, min(100, e));
-  return ldexpf(1.0f, 14 - e);
-}
-
-__device__ __forceinline__ uint32_t pack_f16(float a, float b) {
-  const f16x2 h = {(_Float16)a, (_Float16)b};
-  return *reinterpret_cast<const uint32_t*>(&h);
-}
-
-// split 4 floats (already scaled) into hi / lo fp16 planes, packed 2 x uint32 each
-__device__ __forceinline__ void split4h(const f32x4 t, u32x2& hi, u32x2& lo) {
-  const _Float16 h0 = (_Float16)t.x, h1 = (_Float16)t.y, h2 = (_Float16)t.z, h3 = (_Float16)t.w;
-  const f16x2 a = {h0, h1}, b = {h2, h3};
-  hi = u32x2{*reinterpret_cast<const uint32_t*>(&a), *reinterpret_cast<const uint32_t*>(&b)};
-  lo = u32x2{pack_f16((t.x - (float)h0) * 2048.f, (t.y - (float)h1) * 2048.f),
-             pack_f16((t.z - (float)h2) * 2048.f, (t.w - (float)h3) * 2048.f)};
-}
 
 __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(const GemmHArgs G) {
   __shared__ __attribute__((aligned(16))) uint16_t lds[17408];      // 4 planes (32 KB) | epilogue stage (33.8 KB)
@@ -504,13 +476,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(const GemmHArgs G) {
 // and 12 on one slot - one extra LDS cycle per group, 8 instead of 4 per read (SQ_LDS_BANK_CONFLICT = 3.9 per LDS
 // instruction, profiles/r02/gemm_f16x3_pmc.md).  Pads of 2, 6, 10, 14 slots are conflict-free for all four groups.
 constexpr int AS_BM = 128, AS_PAD = 16;
-
-template <int ACT>
-__device__ __forceinline__ float act_ct(float v, float slope) {
-  if (ACT == 1) return v > 0.f ? v : __expf(v) - 1.0f;
-  if (ACT == 2) return v > 0.f ? v : slope * v;
-  return v;
-}
 
 template <int ACT>
 __global__ __launch_bounds__(512, 1) void gemm_f16x3_as_kernel(const GemmHArgs G) {
@@ -875,7 +840,18 @@ __global__ __launch_bounds__(256) void wsplit_kernel(const float* __restrict__ W
     const _Float16 l = (_Float16)((t - (float)h) * 2048.f);
     // K <= 256 (operands of the A-stationary kernel): fragment-major - the 16 x 32 block of (n-tile, k-step) is stored
     // in MFMA lane order (lane = 16*(k%32/8) + n%16, 8 halfs each), so a wave's fragment load is one contiguous KB
-    const int64_t o = frag ? ((((n >> 4) * (K >> 5) + (k >> 5)) * 64 + (((k & 31) >> 3) << 4) + (n & 15)) << 3) + (k & 7) : r;
+    int64_t o = r;
+    if (frag == 1) {
+      o = ((((n >> 4) * (K >> 5) + (k >> 5)) * 64 + (((k & 31) >> 3) << 4) + (n & 15)) << 3) + (k & 7);
+    } else if (frag == 2) {
+      // DMA-tiled (disgat_gemm_planes): per (256-column step, k-step) one 16 KB block that IS the LDS image of the weight
+      // tile - LDS row rho holds weight row wperm(rho) (gemm_planes.hip), 16-byte chunk c of it at slot c ^ ((rho >> 1) & 3)
+      // - so a DMA piece (16 LDS rows) is 1 KB of consecutive memory: 8 full 128-byte lines instead of 16 half lines
+      const int64_t ns = n >> 8, nl = n & 255, x = nl & 31;
+      const int64_t rho = (nl & ~31) + (((x >> 2) & 1) << 4) + ((x >> 3) << 2) + (x & 3);
+      const int64_t t = k >> 5, c = ((k & 31) >> 3) ^ ((rho >> 1) & 3);
+      o = (((ns * (K >> 5) + t) * 256 + rho) << 5) + (c << 3) + (k & 7);
+    }
     planes[(b * 2 + 0) * kn + o] = *reinterpret_cast<const uint16_t*>(&h);
     planes[(b * 2 + 1) * kn + o] = *reinterpret_cast<const uint16_t*>(&l);
   }
@@ -982,22 +958,36 @@ extern "C" int disgat_gemm_split(const float* A, int64_t lda, int64_t a_batch_st
   return check_launch("gemm_split_kernel");
 }
 
-extern "C" int disgat_split_f16(const float* W, int64_t stride_b, int64_t stride_k, int64_t stride_n, int K, int N, int batch,
-                                uint16_t* planes, float* amax_scale, disgat_stream_t stream) {
-  using namespace disgat;
-  DISGAT_REQUIRE(W && planes && amax_scale && K > 0 && N > 0 && batch > 0, "split_f16: null pointer / bad sizes");
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+namespace disgat {
+static int split_f16_impl(const float* W, int64_t stride_b, int64_t stride_k, int64_t stride_n, int K, int N, int batch,
+                          uint16_t* planes, float* amax_scale, int frag, hipStream_t st) {
   const hipError_t e = hipMemsetAsync(amax_scale, 0, 2 * sizeof(float), st);
   if (e != hipSuccess) return fail((int)e, "split_f16: memset failed: %s", hipGetErrorString(e));
   const int64_t total = (int64_t)batch * K * N;
   const int grid = (int)(total / 256 + 1 < 1024 ? total / 256 + 1 : 1024);
   hipLaunchKernelGGL(wamax_kernel, dim3(grid), dim3(256), 0, st, W, stride_b, stride_k, stride_n, K, N, total,
                      reinterpret_cast<uint32_t*>(amax_scale));
-  // layout rule shared with disgat_gemm_f16x3: K <= 256 selects its A-stationary kernel, which reads fragment-major planes
-  const int frag = (K <= 256 && K % 32 == 0 && N % 16 == 0) ? 1 : 0;
   hipLaunchKernelGGL(wsplit_kernel, dim3(grid), dim3(256), 0, st, W, stride_b, stride_k, stride_n, K, N, total, amax_scale,
                      planes, amax_scale + 1, frag);
   return check_launch("wsplit_kernel");
+}
+}  // namespace disgat
+
+extern "C" int disgat_split_f16(const float* W, int64_t stride_b, int64_t stride_k, int64_t stride_n, int K, int N, int batch,
+                                uint16_t* planes, float* amax_scale, disgat_stream_t stream) {
+  using namespace disgat;
+  DISGAT_REQUIRE(W && planes && amax_scale && K > 0 && N > 0 && batch > 0, "split_f16: null pointer / bad sizes");
+  // layout rule shared with disgat_gemm_f16x3: K <= 256 selects its A-stationary kernel, which reads fragment-major planes
+  const int frag = (K <= 256 && K % 32 == 0 && N % 16 == 0) ? 1 : 0;
+  return split_f16_impl(W, stride_b, stride_k, stride_n, K, N, batch, planes, amax_scale, frag, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int disgat_split_f16_rm(const float* W, int64_t stride_b, int64_t stride_k, int64_t stride_n, int K, int N, int batch,
+                                   uint16_t* planes, float* amax_scale, disgat_stream_t stream) {
+  using namespace disgat;
+  DISGAT_REQUIRE(W && planes && amax_scale && K > 0 && N > 0 && batch > 0, "split_f16_rm: null pointer / bad sizes");
+  DISGAT_REQUIRE(N % 256 == 0 && K % 32 == 0, "split_f16_rm: N=%d must be a multiple of 256 and K=%d of 32", N, K);
+  return split_f16_impl(W, stride_b, stride_k, stride_n, K, N, batch, planes, amax_scale, 2, reinterpret_cast<hipStream_t>(stream));
 }
 
 extern "C" int disgat_amax(const float* A, int64_t lda, int64_t a_batch_stride, int M, int K, int batch, float* out,

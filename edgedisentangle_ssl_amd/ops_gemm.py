@@ -88,6 +88,102 @@ def presplit(w):
     return split_weight_f16(w)
 
 
+class Planes:
+    """An fp32 operand stored ALREADY SPLIT for the f16x3 GEMMs: `hi`, `lo` int16 views of fp16 planes with the logical
+    tensor's shape and strides (2-D [M,K], or a head-batched [H,M,K] view of an [M,H,K] buffer), `bound` a device
+    scalar >= max |v| - producer and consumer derive the common power-of-two scale from it (csrc/gemm_common.h)."""
+    __slots__ = ("hi", "lo", "bound")
+
+    def __init__(self, hi, lo, bound):
+        self.hi, self.lo, self.bound = hi, lo, bound
+
+    @property
+    def shape(self):
+        return self.hi.shape
+
+    def dim(self):
+        return self.hi.dim()
+
+    def view_heads(self, nh):
+        """[M, nh*K] planes as the head-batched [nh, M, K] view."""
+        m, hk = self.hi.shape
+        return Planes(self.hi.view(m, nh, hk // nh).permute(1, 0, 2), self.lo.view(m, nh, hk // nh).permute(1, 0, 2), self.bound)
+
+    def to_f32(self):
+        """(hi + lo 2^-11) / s as a fresh fp32 tensor (every element to 2^-23 of itself)."""
+        h = self.hi
+        b = h.dim() == 3
+        hb, m, k = (h.shape if b else (1,) + tuple(h.shape))
+        out = torch.empty((m, hb, k) if b else (m, k), dtype=torch.float32, device=h.device)
+        ov = out.permute(1, 0, 2) if b else out
+        _lib.call("disgat_planes_to_f32", h.data_ptr(), self.lo.data_ptr(), h.stride(-2), h.stride(0) if b else 0, m, k, hb,
+                  self.bound.data_ptr(), ov.data_ptr(), ov.stride(-2), ov.stride(0) if b else 0, ops._stream())
+        return ov if b else out
+
+
+def planes_ok(k, n):
+    """Shapes disgat_gemm_planes takes (its tiling: 256 output columns per step, 32-deep k-steps)."""
+    return mode() == "f16x3" and n % 256 == 0 and k % 32 == 0 and k >= 64
+
+
+def split_planes(x, bound=None):
+    """fp32 [M,K] or head-batched [H,M,K] view -> Planes with the same logical layout (contiguous [M,K] / [M,H,K])."""
+    b = x.dim() == 3
+    hb, m, k = (x.shape if b else (1,) + tuple(x.shape))
+    if bound is None:
+        bound = amax(x)
+    hi = torch.empty((m, hb, k) if b else (m, k), dtype=torch.int16, device=x.device)
+    lo = torch.empty_like(hi)
+    hv, lv = (hi.permute(1, 0, 2), lo.permute(1, 0, 2)) if b else (hi, lo)
+    _lib.call("disgat_split_planes", x.data_ptr(), x.stride(-2), x.stride(0) if b else 0, m, k, hb, bound.data_ptr(),
+              hv.data_ptr(), lv.data_ptr(), hv.stride(-2), hv.stride(0) if b else 0, ops._stream())
+    return Planes(hv, lv, bound)
+
+
+def presplit_rm(w):
+    """Row-major [.., 2, N, K] weight planes + scale for disgat_gemm_planes (any K); None when it cannot take the shape."""
+    if not w.is_cuda or not planes_ok(w.shape[-2], w.shape[-1]):
+        return None
+    w = w.detach()
+    if w.dim() == 2:
+        w = w.unsqueeze(0)
+    hb, k, n = w.shape
+    planes = torch.empty((hb, 2, n, k), dtype=torch.int16, device=w.device)
+    amax_scale = torch.empty(2, dtype=torch.float32, device=w.device)
+    _lib.call("disgat_split_f16_rm", w.data_ptr(), w.stride(0), w.stride(1), w.stride(2), k, n, hb, planes.data_ptr(),
+              amax_scale.data_ptr(), ops._stream())
+    return planes, amax_scale[1:]
+
+
+def linear_planes(ap, w_rm, n, bias=None, init=None, act=ACT_NONE, slope=0.01, want_f32=True, out_bound=None):
+    """act(A @ W + bias + init) with A given as Planes (no autograd: inference forwards only).  w_rm = presplit_rm(W).
+    Returns (fp32 [M, H*N] or None, Planes [M, H*N] or None): the plane output (scaled by `out_bound`, a device scalar
+    bounding |result|) is what the next GEMM of the chain consumes."""
+    batched = ap.dim() == 3
+    hb, m, k = (ap.shape if batched else (1,) + tuple(ap.shape))
+    planes, b_scale = w_rm
+    dev = ap.hi.device
+    out = torch.empty((m, hb * n), dtype=torch.float32, device=dev) if want_f32 else None
+    oh = ol = None
+    if out_bound is not None:
+        oh = torch.empty((m, hb * n), dtype=torch.int16, device=dev)
+        ol = torch.empty_like(oh)
+    init_bs = n if batched else 0
+    if init is not None and batched and init.shape == (m, n) and init.stride(-1) == 1:
+        init_bs = 0
+    elif init is not None and (init.stride(-1) != 1 or tuple(init.shape) != (m, hb * n)):
+        init = init.expand(m, hb * n).contiguous()
+    if bias is not None:
+        bias = bias.contiguous()
+    ops._launch("disgat_gemm_planes", "gemm_f16x3", 2.0 * m * n * k * hb,
+                ap.hi.data_ptr(), ap.lo.data_ptr(), ap.hi.stride(-2), ap.hi.stride(0) if batched else 0, planes.data_ptr(),
+                ap.bound.data_ptr(), b_scale.data_ptr(), ops._ptr(bias), ops._ptr(init),
+                0 if init is None else init.stride(0), init_bs, ops._ptr(out), hb * n, n if batched else 0,
+                ops._ptr(oh), ops._ptr(ol), hb * n, n if batched else 0, ops._ptr(out_bound), m, n, k, hb, act, float(slope),
+                ops._stream())
+    return out, (None if oh is None else Planes(oh, ol, out_bound))
+
+
 def _forward(a, w, bias, init, act, slope, a_amax=None, w_split=None):
     batched = a.dim() == 3
     if batched:

@@ -213,6 +213,41 @@ int disgat_amax(const float* A, int64_t lda, int64_t a_batch_stride, int M, int 
 int disgat_split_f16(const float* W, int64_t stride_b, int64_t stride_k, int64_t stride_n, int K, int N, int batch,
                      uint16_t* planes, float* amax_scale, disgat_stream_t stream);
 
+/* disgat_split_f16 with the row-major [N][K] plane order for every K: the weight operand of disgat_gemm_planes. */
+int disgat_split_f16_rm(const float* W, int64_t stride_b, int64_t stride_k, int64_t stride_n, int K, int N, int batch,
+                        uint16_t* planes, float* amax_scale, disgat_stream_t stream);
+
+/* The f16x3 contraction with an A operand that arrives ALREADY SPLIT - written as two fp16 planes by the kernel that
+ * produced it (disgat_edge_fwd with Z_hi / Z_lo, this launcher's own plane output, or disgat_split_planes):
+ *   A_hi, A_lo [batch][M][K] fp16 (row stride lda halfs, batch stride a_batch_stride halfs) = hi, lo of A * s_A with
+ *   s_A = the power of two that puts *a_bound in [2^13, 2^14) - producer and consumer read the same device scalar;
+ *   Bt_planes from disgat_split_f16_rm, b_scale = its amax_scale + 1; bias / init / act / slope as disgat_gemm_f16x3.
+ * Outputs, either or both: C fp32 (row stride ldc); C_hi / C_lo planes of C * s_C (row stride ldp halfs), s_C from
+ * *c_bound (an upper bound of max |C|, e.g. a_bound x the largest column abs-sum of B + max |bias|): the A operand of
+ * the next GEMM of the chain.  N % 256 == 0, K % 32 == 0, K >= 64; plane rows 16-byte aligned.
+ * Replaces, on forwards that record no autograd graph, the same torch.mm / nn.Linear calls as disgat_gemm_f16x3
+ * (layers.py:397-399 per-head projection, :905 FuseLayer, models.py:538 DifHead classifier). */
+int disgat_gemm_planes(const uint16_t* A_hi, const uint16_t* A_lo, int64_t lda, int64_t a_batch_stride,
+                       const uint16_t* Bt_planes, const float* a_bound, const float* b_scale, const float* bias,
+                       const float* init, int64_t ldi, int64_t init_batch_stride, float* C, int64_t ldc,
+                       int64_t c_batch_stride, uint16_t* C_hi, uint16_t* C_lo, int64_t ldp, int64_t p_batch_stride,
+                       const float* c_bound, int M, int N, int K, int batch, int act, float slope,
+                       disgat_stream_t stream);
+
+/* fp32 X [batch][M][K] -> planes P_hi, P_lo (hi, lo of X * s, s from *bound >= max |X|); and back:
+ * X = (P_hi + P_lo * 2^-11) / s.  K and every stride multiples of 4. */
+int disgat_split_planes(const float* X, int64_t ldx, int64_t x_batch_stride, int M, int K, int batch,
+                        const float* bound, uint16_t* P_hi, uint16_t* P_lo, int64_t ldp, int64_t p_batch_stride,
+                        disgat_stream_t stream);
+int disgat_planes_to_f32(const uint16_t* P_hi, const uint16_t* P_lo, int64_t ldp, int64_t p_batch_stride, int M, int K,
+                         int batch, const float* bound, float* X, int64_t ldx, int64_t x_batch_stride,
+                         disgat_stream_t stream);
+
+/* Diagnostic: with DISGAT_PL_DEBUG & 32 disgat_gemm_planes accumulates s_memtime cycles per loop phase of waves 0 and 4 of
+ * every block ([2][8]: wait, barrier, fragment reads + DMA issue, MFMA, epilogue, unit set-up); copies them out
+ * (out16 may be NULL) and optionally zeroes them.  Synchronises the device. */
+int disgat_debug_stamps(unsigned long long* out16, int reset);
+
 /* Backward of the epilogue activation from the saved output (n contiguous floats, n % 4 == 0):
  * gin = g * (out > 0 ? 1 : (act == 1 ? out + 1 : slope)); act 1 = ELU, 2 = leaky ReLU.  gin may alias g.
  * amax_out (or NULL): receives max |gin|, the scale input of the GEMMs that consume gin. */
