@@ -87,8 +87,8 @@ _SIGS = {
     "disgat_last_error": (_c.c_char_p, []),
     "disgat_edge_fwd": (_c.c_int, [_c.c_int, _P, _c.c_int, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
                                    _P, _c.c_int, _P, _c.c_int, _P, _c.c_int, _P, _P, _P, _P, _P, _P, _c.c_int,
-                                   _c.c_float, _c.c_uint64, _P, _P, _P]),
-    "disgat_edge_combine": (_c.c_int, [_P, _P, _c.c_int, _c.c_int, _c.c_int, _P, _P, _P, _P, _c.c_int, _P]),
+                                   _c.c_float, _c.c_uint64, _P, _P, _P, _P, _P, _P]),
+    "disgat_edge_combine": (_c.c_int, [_P, _P, _c.c_int, _c.c_int, _c.c_int, _P, _P, _P, _P, _c.c_int, _P, _P, _P, _P]),
     "disgat_aux_score": (_c.c_int, [_c.c_int, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
                                     _c.c_int, _P, _c.c_int, _P, _c.c_int, _P, _c.c_int, _P, _P, _P, _P]),
     "disgat_pair_loss": (_c.c_int, [_P, _c.c_int64, _c.c_int, _c.c_int, _P, _P, _P, _P]),

@@ -24,7 +24,7 @@
 //          h = x W per head - the dot product runs over F_out instead of F_in, so the layer input may be arbitrarily
 //          wide (raw bag-of-words features, --origin_feat); lane map, operand layout and padding of att 3
 //          (rowop = colop = h [N][H*F_out]), no `a`, no nonlinearity.
-#include "disgat_common.h"
+#include "gemm_common.h"
 
 namespace disgat {
 
@@ -51,6 +51,9 @@ struct EdgeFwdArgs {
   uint32_t* sign;       // att 3, optional: [E][64] sign words (disgat_common.h) for the backward pass
   const float* e_in;    // optional [H][E]: added to the score before the sigmoid (partial scores of a head whose
                         // features are spread over several launches: heads wider than one launch's 1024 features)
+  uint16_t* Zh;         // optional: Z as the two fp16 planes of the f16x3 GEMM that consumes it (gemm_planes.hip), same
+  uint16_t* Zl;         // [N][H][F_in] order, instead of fp32 Z - same bytes, and the consumer splits nothing
+  const float* z_bound; // device scalar >= max |Z| (an analytic bound: Z rows are convex combinations of x rows)
 };
 
 template <int ATT, int HL, int QN, int XN>
@@ -245,13 +248,30 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void edge_fwd_kernel(const EdgeFwd
     // SageConv divides the aggregate by rowsum(attention)+1 (layers.py:103), attention taken AFTER
     // dropout (layers.py:394, 402): rowsum = dsum*inv
     if (A.sage_div) inv = inv / (dsum * inv + 1.0f);
-    float* zp = A.Z + (size_t)row * (H * A.F_in) + xoff;
+    if (A.Zh != nullptr) {
+      const float sz = f16_scale(*A.z_bound);
+      const size_t zo = (size_t)row * (H * A.F_in) + xoff;
 #pragma unroll
-    for (int hh = 0; hh < H; ++hh) {
-      const float sc = readlane_f(inv, head_lane(hh));
+      for (int hh = 0; hh < H; ++hh) {
+        const float sc = readlane_f(inv, head_lane(hh)) * sz;
 #pragma unroll
-      for (int i = 0; i < XN; ++i)
-        if (i * 256 + xoff < A.F_in) st4(zp + hh * A.F_in + i * 256, zacc[hh * XN + i] * sc);
+        for (int i = 0; i < XN; ++i)
+          if (i * 256 + xoff < A.F_in) {
+            u32x2 h, l;
+            split4h(zacc[hh * XN + i] * sc, h, l);
+            *reinterpret_cast<u32x2*>(A.Zh + zo + hh * A.F_in + i * 256) = h;
+            *reinterpret_cast<u32x2*>(A.Zl + zo + hh * A.F_in + i * 256) = l;
+          }
+      }
+    } else {
+      float* zp = A.Z + (size_t)row * (H * A.F_in) + xoff;
+#pragma unroll
+      for (int hh = 0; hh < H; ++hh) {
+        const float sc = readlane_f(inv, head_lane(hh));
+#pragma unroll
+        for (int i = 0; i < XN; ++i)
+          if (i * 256 + xoff < A.F_in) st4(zp + hh * A.F_in + i * 256, zacc[hh * XN + i] * sc);
+      }
     }
     if (A.den != nullptr && ((ATT != 1) ? ((lane & (G - 1)) == 0) : (lane < H))) {
       A.den[(size_t)row * (2 * H) + myh] = den;
@@ -276,7 +296,9 @@ __global__ __launch_bounds__(256) void edge_combine_kernel(const int32_t* __rest
                                                            const int32_t* __restrict__ split_ptr, int H, int F_in,
                                                            const float* __restrict__ part_z,
                                                            const float* __restrict__ part_den, float* __restrict__ Z,
-                                                           float* __restrict__ den_out, int sage_div) {
+                                                           float* __restrict__ den_out, int sage_div,
+                                                           uint16_t* __restrict__ Zh, uint16_t* __restrict__ Zl,
+                                                           const float* __restrict__ z_bound) {
   const int s = blockIdx.x;
   const int row = split_rows[s];
   const int s0 = split_ptr[s], s1 = split_ptr[s + 1];
@@ -305,7 +327,14 @@ __global__ __launch_bounds__(256) void edge_combine_kernel(const int32_t* __rest
     }
     float inv = (den > 0.f) ? 1.0f / den : 0.f;
     if (sage_div) inv = inv / (dsum * inv + 1.0f);
-    st4(Z + (size_t)row * HF + idx, acc * inv);
+    if (Zh != nullptr) {
+      u32x2 h, l;
+      split4h(acc * (inv * f16_scale(*z_bound)), h, l);
+      *reinterpret_cast<u32x2*>(Zh + (size_t)row * HF + idx) = h;
+      *reinterpret_cast<u32x2*>(Zl + (size_t)row * HF + idx) = l;
+    } else {
+      st4(Z + (size_t)row * HF + idx, acc * inv);
+    }
     if (den_out != nullptr && idx % F_in == 0) {
       den_out[(size_t)row * (2 * H) + h] = den;
       den_out[(size_t)row * (2 * H) + H + h] = dsum;
@@ -375,7 +404,8 @@ extern "C" int disgat_edge_fwd(int att, const int32_t* items, int n_items, const
                                int F_in, int F_out, const float* x, int ldx, const float* rowop, int ld_row,
                                const float* colop, int ld_col, const float* a, float* Z, float* edge_e, float* den,
                                float* part_z, float* part_den, int sage_div, float drop_p, uint64_t drop_seed,
-                               uint32_t* sign_bits, const float* e_in, disgat_stream_t stream) {
+                               uint32_t* sign_bits, const float* e_in, uint16_t* Z_hi, uint16_t* Z_lo, const float* z_bound,
+                               disgat_stream_t stream) {
   using namespace disgat;
   DISGAT_REQUIRE(att >= 1 && att <= 4, "edge_fwd: att=%d not in 1..3 (4 = att 2 over projected operands)", att);
   DISGAT_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "edge_fwd: dropout p=%f outside [0,1)", (double)drop_p);
@@ -384,8 +414,10 @@ extern "C" int disgat_edge_fwd(int att, const int32_t* items, int n_items, const
   const int hl = ilog2_exact(H);
   DISGAT_REQUIRE(hl >= 1 && hl <= 4, "edge_fwd: H=%d must be a power of two in [2,16]", H);
   DISGAT_REQUIRE(F_in > 0 && F_in % 4 == 0 && ldx % 4 == 0 && ldx >= F_in, "edge_fwd: F_in=%d ldx=%d must be multiples of 4", F_in, ldx);
-  DISGAT_REQUIRE(items && x && rowop && Z && (E == 0 || (col && edge_e)), "edge_fwd: null pointer");   // E == 0: rows are only zero-filled
+  DISGAT_REQUIRE(items && x && rowop && (Z || Z_hi) && (E == 0 || (col && edge_e)), "edge_fwd: null pointer");   // E == 0: rows are only zero-filled
   DISGAT_REQUIRE(aligned16(items) && aligned16(x) && aligned16(Z), "edge_fwd: items/x/Z must be 16-byte aligned");
+  DISGAT_REQUIRE((Z_hi == nullptr) == (Z_lo == nullptr) && (Z_hi == nullptr || (z_bound != nullptr && aligned16(Z_hi) && aligned16(Z_lo))),
+                 "edge_fwd: Z_hi, Z_lo (16-byte aligned) and z_bound go together");
   const int xn = (F_in + 255) / 256;
   int qn = 1;
   if (att == 3 || att == 4) {
@@ -403,7 +435,7 @@ extern "C" int disgat_edge_fwd(int att, const int32_t* items, int n_items, const
   EdgeFwdArgs args{reinterpret_cast<const int4*>(items), n_items, col, E, N, F_in, x, ldx, rowop, ld_row, colop, ld_col,
                    a, Z, edge_e, den, part_z, part_den, sage_div,
                    DropCfg{drop_seed, (uint32_t)((double)drop_p * 4294967296.0), 1.0f / (1.0f - drop_p)},
-                   att == 3 ? sign_bits : nullptr, e_in};
+                   att == 3 ? sign_bits : nullptr, e_in, Z_hi, Z_lo, z_bound};
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   switch (att) {
     case 1: return launch_edge_h<1>(hl, qn, xn, args, s);
@@ -415,12 +447,12 @@ extern "C" int disgat_edge_fwd(int att, const int32_t* items, int n_items, const
 
 extern "C" int disgat_edge_combine(const int32_t* split_rows, const int32_t* split_ptr, int n_split, int H, int F_in,
                                    const float* part_z, const float* part_den, float* Z, float* den, int sage_div,
-                                   disgat_stream_t stream) {
+                                   uint16_t* Z_hi, uint16_t* Z_lo, const float* z_bound, disgat_stream_t stream) {
   using namespace disgat;
   if (n_split == 0) return 0;
   DISGAT_REQUIRE(n_split > 0 && H > 0 && F_in > 0 && F_in % 4 == 0, "edge_combine: bad sizes");
-  DISGAT_REQUIRE(split_rows && split_ptr && part_z && part_den && Z, "edge_combine: null pointer");
+  DISGAT_REQUIRE(split_rows && split_ptr && part_z && part_den && (Z || (Z_hi && Z_lo && z_bound)), "edge_combine: null pointer");
   hipLaunchKernelGGL(edge_combine_kernel, dim3(n_split), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), split_rows,
-                     split_ptr, H, F_in, part_z, part_den, Z, den, sage_div);
+                     split_ptr, H, F_in, part_z, part_den, Z, den, sage_div, Z_hi, Z_lo, z_bound);
   return check_launch("edge_combine_kernel");
 }

@@ -57,6 +57,9 @@ constexpr int PL_BM = 128, PL_BN = 256;
 constexpr int PL_A_SLOT = 2 * PL_BM * 64;     // bytes: 2 planes x 128 rows x 32 halfs
 constexpr int PL_B_SLOT = 2 * PL_BN * 64;
 
+#ifndef DISGAT_PL_DIAG
+#define DISGAT_PL_DIAG 0      // 1: ablation switches (GemmPArgs::dbg) and s_memtime phase stamps compiled in (tools/gp_*.py)
+#endif
 __device__ unsigned long long pl_stamps[16];     // diagnostic (DISGAT_PL_DEBUG & 32): cycles per loop phase, [role][phase]
 
 template <int N>
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(512, 1) void gemm_planes_kernel(const GemmPArgs G) 
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       int row = min(m0 + 64 * (lw & 1) + 16 * j + lrow, G.M - 1);      // rows past M: valid memory, never stored
-      if (G.dbg & 4) row &= 127;
+      if (DISGAT_PL_DIAG && (G.dbg & 4)) row &= 127;
       pa[j] = base + (int64_t)row * G.lda;
     }
   };
@@ -189,7 +192,7 @@ __global__ __launch_bounds__(512, 1) void gemm_planes_kernel(const GemmPArgs G) 
   const int fo = (lane & 15) * 64 + (((lane >> 4) ^ (((lane & 15) >> 1) & 3)) << 4);
   int sa = 0, sb = 0;                                  // ring slots of the current k-step
   bool relax = false;                                  // previous unit ended with a full epilogue (exactly S_L stores)
-  const bool stamp_on = (G.dbg & 32) != 0;
+  const bool stamp_on = DISGAT_PL_DIAG && (G.dbg & 32) != 0;
   unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_prev = 0;
   auto stamp = [&](int ph) __attribute__((always_inline)) {
     if (!stamp_on) return;
@@ -273,31 +276,32 @@ __global__ __launch_bounds__(512, 1) void gemm_planes_kernel(const GemmPArgs G) 
       // per 16-row tile: hi*hi, (weight lo) x (A hi), (weight hi) x (A lo) - 12 MFMAs on one pair of A fragments, the next
       // tile's pair requested before them (left to the compiler each tile read its fragments, waited, then computed:
       // 24 cycles per MFMA instead of 16)
-      f16x8 fah[2];
-      fah[0] = *reinterpret_cast<const f16x8*>(Ab);
+      f16x8 fa[2][2];
+      fa[0][0] = *reinterpret_cast<const f16x8*>(Ab);
+      fa[0][1] = *reinterpret_cast<const f16x8*>(Ab + PL_BM * 64);
       auto rows = [&](auto lo_c, auto hi_c) __attribute__((always_inline)) {
         static_for<decltype(hi_c)::value - decltype(lo_c)::value>([&](auto ic) __attribute__((always_inline)) {
           constexpr int i = decltype(lo_c)::value + decltype(ic)::value;
           constexpr int cur = i & 1, nxt = cur ^ 1;
-          // this tile's lo fragment (first used 8 MFMAs from here) and the next tile's hi fragment (a loader's last
-          // prefetch reads a tile it does not use: valid LDS, harmless)
-          const f16x8 fal = *reinterpret_cast<const f16x8*>(Ab + PL_BM * 64 + i * 1024);
-          if constexpr (i + 1 < MC) fah[nxt] = *reinterpret_cast<const f16x8*>(Ab + (i + 1) * 1024);
+          if constexpr (i + 1 < MC) {      // (a loader's last prefetch reads a tile it does not use: valid LDS, harmless)
+            fa[nxt][0] = *reinterpret_cast<const f16x8*>(Ab + (i + 1) * 1024);
+            fa[nxt][1] = *reinterpret_cast<const f16x8*>(Ab + PL_BM * 64 + (i + 1) * 1024);
+          }
           __builtin_amdgcn_sched_barrier(0);       // keep the requests ahead of this tile's MFMAs
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], fah[cur], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], fa[cur][0], acc[i][j], 0, 0, 0);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], fah[cur], acx[i][j], 0, 0, 0);
+          for (int j = 0; j < 4; ++j) acx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], fa[cur][0], acx[i][j], 0, 0, 0);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], fal, acx[i][j], 0, 0, 0);
+          for (int j = 0; j < 4; ++j) acx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], fa[cur][1], acx[i][j], 0, 0, 0);
         });
       };
       __builtin_amdgcn_s_setprio(1);
-      if (!(G.dbg & 2)) {
+      if (!(DISGAT_PL_DIAG && (G.dbg & 2))) {
         rows(std::integral_constant<int, 0>{}, std::integral_constant<int, ML>{});
         if (!ld_wave) rows(std::integral_constant<int, ML>{}, std::integral_constant<int, MC>{});
       } else {
-        asm volatile("" ::"v"(fah[0]), "v"(bh[0]), "v"(bh[1]), "v"(bh[2]), "v"(bh[3]), "v"(bl[0]), "v"(bl[1]), "v"(bl[2]), "v"(bl[3]));
+        asm volatile("" ::"v"(fa[0][0]), "v"(fa[0][1]), "v"(bh[0]), "v"(bh[1]), "v"(bh[2]), "v"(bh[3]), "v"(bl[0]), "v"(bl[1]), "v"(bl[2]), "v"(bl[3]));
       }
       __builtin_amdgcn_s_setprio(0);
     }
@@ -305,7 +309,7 @@ __global__ __launch_bounds__(512, 1) void gemm_planes_kernel(const GemmPArgs G) 
     stamp(3);
     // ---- epilogue: acc[i][j][r] = C[row0 + 16 i][col0 + 32 (j >> 1) + 4 (j & 1) + r]
     const bool full = m0 + PL_BM <= G.M;
-    if (G.dbg & 1) {
+    if (DISGAT_PL_DIAG && (G.dbg & 1)) {
 #pragma unroll
       for (int i = 0; i < MC; ++i)
 #pragma unroll
@@ -317,7 +321,7 @@ __global__ __launch_bounds__(512, 1) void gemm_planes_kernel(const GemmPArgs G) 
 #pragma unroll
       for (int i = decltype(lo_c)::value; i < decltype(hi_c)::value; ++i) {
         const int row = row0 + 16 * i;
-        const bool ok = (full || row < G.M) && !(G.dbg & 8);
+        const bool ok = (full || row < G.M) && !(DISGAT_PL_DIAG && (G.dbg & 8));
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
           float v[8];

@@ -120,6 +120,9 @@ class HeadList(list):
     fused = None
     fused_amax = None
     pre_elu = None
+    planes = None       # ops_gemm.Planes of the same [N, H*F_out] buffer (no-graph forwards): what FuseLayer / the DifHead
+    n_heads = 0         # classifier GEMMs consume.  With `heads_planes` the fp32 buffer is never written and the list is
+    f_out = 0           # EMPTY: only a consumer that asked for planes may receive such a list (DISGAT._run checks).
 
 
 MAX_HEAD_SLICE = 1024      # att 3 / 4: features of one head a single launch scores (2 heads x 32 lanes x 8 float4)
@@ -221,7 +224,13 @@ def _pack_score_operands(layers, x, x_all, att, H, Hp, f_in, f_out, fp, am=None,
     return ops_gemm.linear(x, wt, a_amax=am, w_split=st), ops_gemm.linear(x_all, wb, a_amax=am, w_split=sb), a_vec
 
 
-def disga_heads(layers, x, adj, aux_indices=None, head_ranges=None, aux_only=False):
+def _no_graph(layers, x):
+    """True when this forward records no autograd graph (inference / torch.no_grad()): the plane-operand GEMM chain
+    (ops_gemm.linear_planes, no backward) may replace the differentiable one."""
+    return not (torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for l in layers for p in l.parameters())))
+
+
+def disga_heads(layers, x, adj, aux_indices=None, head_ranges=None, aux_only=False, heads_planes=False):
     """All H heads of one DISGAT layer: the loop of models.py:225-228 as ONE fused edge pass.
 
     layers: the H DisGALayer modules (parameter holders).  adj: torch sparse COO or CSRGraph.
@@ -229,6 +238,8 @@ def disga_heads(layers, x, adj, aux_indices=None, head_ranges=None, aux_only=Fal
     optional list of (lo,hi) per aux list restricting which heads are scored on it (DisEdge uses
     half the heads per list, pretrainer.py:619-620); unscored heads' entries are None.
     aux_only: score the aux pairs only (no edge pass, no aggregation): returns (None, None, aux).
+    heads_planes: the caller's consumer of the heads takes ops_gemm.Planes (our FuseLayer, the DifHead classifier): on
+    a no-graph forward the head buffer is then written ONLY as planes (HeadList.planes; the list itself stays empty).
     Returns (HeadList of elu(h') [N,F_out], [edge_e[E,1]]*H, [[aux_e[M_l,1]]_l]*H or None).
     """
     l0 = layers[0]
@@ -317,6 +328,11 @@ def disga_heads(layers, x, adj, aux_indices=None, head_ranges=None, aux_only=Fal
     merged_aux = None
     merge = rec and not aux_only and aux_indices and n_groups == 1 and f_in_p <= tile and len(f_slices) == 1
     heads = e_list = None
+    concat = all(l.concat for l in layers)
+    # plane-operand chain (csrc/gemm_planes.hip): edge pass -> Z planes -> projection -> head planes -> fuser.  One head
+    # group, no column / feature slices, widths the kernel tiles (K = F_in a multiple of 32, 256 output columns per step)
+    use_pl = (not aux_only and z_bound is not None and n_groups == 1 and len(f_slices) == 1 and f_in_p == f_in
+              and f_in_p <= tile and concat and ops_gemm.planes_ok(f_in, f_out) and _no_graph(layers, x))
     if not aux_only:
         z_groups, e_groups = [], []
         for gi in range(n_groups):
@@ -326,6 +342,10 @@ def disga_heads(layers, x, adj, aux_indices=None, head_ranges=None, aux_only=Fal
                                for li in range(len(aux_indices)))
                 cfg = (graph, att, Hk, f_in_p, fp, gnn == "SAGE", d, ranges)
                 z, edge_e, _den, *merged_aux = ops.LayerPass.apply(xg, r, c, av, cfg, *aux_indices)
+            elif use_pl:
+                # no-graph forward: the aggregate leaves the edge pass as the two fp16 planes the projection GEMM consumes
+                z, edge_e, _den = ops.edge_forward(graph, att, Hk, f_in_p, fp, xg, r, c, av, gnn == "SAGE", d, need_den=False,
+                                                   z_bound=z_bound.reshape(1))
             elif f_in_p <= tile:
                 cfg = (graph, att, Hk, f_in_p, fp, gnn == "SAGE", d, rec)
                 e_in = earlier_slices(gi, graph.edge_pairs(), 0, Hk) if len(f_slices) > 1 else None
@@ -347,10 +367,43 @@ def disga_heads(layers, x, adj, aux_indices=None, head_ranges=None, aux_only=Fal
 
         # ---- per-head output projection on the aggregated neighbourhood (dense, MFMA), written
         # straight into the fused [N, H*F_out] layout the fuser consumes (no torch.cat of heads)
-        zt = z[:, :H, :f_in].permute(1, 0, 2)                               # [H,N,F_in] strided view
-        concat = all(l.concat for l in layers)
         act_code = ops_gemm.ACT_ELU if concat else ops_gemm.ACT_NONE         # ELU fused in the GEMM epilogue
-        if gnn == "AT":                                                      # layers.py:397-399
+        if use_pl:
+            zp = ops_gemm.Planes(z.hi[:, :H].permute(1, 0, 2), z.lo[:, :H].permute(1, 0, 2), z.bound)   # [H,N,F_in] views
+            bias = init = None
+            if gnn == "AT":                                                  # layers.py:397-399
+                def pack_at_pl():
+                    w = torch.stack([l.W_em for l in layers])
+                    return ops_gemm.presplit_rm(w), w.detach().abs().sum(1).max()
+                wr, wnorm = _memo(layers, "proj_AT_pl", pack_at_pl)
+                pre_bound = z_bound * wnorm
+            elif gnn == "SAGE":                                              # layers.py:96-110
+                def pack_sage_pl():
+                    wx = torch.cat([l.ag_layer.proj.weight[:, :f_in].t() for l in layers], dim=1)
+                    wn = torch.stack([l.ag_layer.proj.weight[:, f_in:].t() for l in layers])
+                    return wx.contiguous(), ops_gemm.presplit(wx), ops_gemm.presplit_rm(wn), wn.detach().abs().sum(1).max(), wx.detach().abs().sum(0).max()
+                wx, wxs, wr, wn_norm, wx_norm = _memo(layers, "proj_SAGE_pl", pack_sage_pl)
+                init = ops_gemm.linear(x, wx, a_amax=am_x, w_split=wxs)
+                pre_bound = z_bound * wn_norm + am_x * wx_norm
+            else:                                                            # layers.py:38-54
+                def pack_gcn_pl():
+                    w = torch.stack([l.ag_layer.weight for l in layers])
+                    b = torch.cat([l.ag_layer.bias for l in layers]).contiguous()
+                    return ops_gemm.presplit_rm(w), b, w.detach().abs().sum(1).max(), b.detach().abs().max()
+                wr, bias, wnorm, bnorm = _memo(layers, "proj_GCN_pl", pack_gcn_pl)
+                pre_bound = z_bound * wnorm + bnorm
+            h_bound = torch.clamp(pre_bound * 1.001, min=1.0).reshape(1)     # |elu(v)| <= max(|v|, 1)
+            act, hpl = ops_gemm.linear_planes(zp, wr, f_out, bias, init, act_code, 0.01, want_f32=not heads_planes, out_bound=h_bound)
+            heads = HeadList() if act is None else HeadList(act[:, h * f_out:(h + 1) * f_out] for h in range(H))
+            heads.fused, heads.planes, heads.fused_amax = act, hpl, h_bound
+            heads.n_heads, heads.f_out = H, f_out
+            e_list = [edge_e[h].unsqueeze(1) for h in range(H)]
+            zt = None
+        else:
+            zt = z[:, :H, :f_in].permute(1, 0, 2)                           # [H,N,F_in] strided view
+        if use_pl:
+            pass
+        elif gnn == "AT":                                                    # layers.py:397-399
             def pack_at():
                 w = torch.stack([l.W_em for l in layers])                    # [H,F_in,F_out]
                 return w, ops_gemm.presplit(w), w.detach().abs().sum(1).max()
@@ -369,14 +422,15 @@ def disga_heads(layers, x, adj, aux_indices=None, head_ranges=None, aux_only=Fal
             b = torch.cat([l.ag_layer.bias for l in layers])                 # [H*F_out]
             fused = ops_gemm.linear(zt, w, b, None, act_code, a_amax=z_bound)
             pre_bound = None if z_bound is None else z_bound * w.detach().abs().sum(1).max() + b.detach().abs().max()
-        act = fused if concat else F.elu(fused)                              # layers.py:508-509
-        heads = HeadList(act[:, h * f_out:(h + 1) * f_out] for h in range(H))
-        heads.fused = act
-        # |elu(v)| <= max(|v|, 1)
-        heads.fused_amax = None if pre_bound is None else torch.clamp(pre_bound * 1.001, min=1.0).reshape(1)
-        heads.pre_elu = None if concat else [fused[:, h * f_out:(h + 1) * f_out] for h in range(H)]
-
-        e_list = [edge_e[h].unsqueeze(1) for h in range(H)]
+        if not use_pl:
+            act = fused if concat else F.elu(fused)                          # layers.py:508-509
+            heads = HeadList(act[:, h * f_out:(h + 1) * f_out] for h in range(H))
+            heads.fused = act
+            heads.n_heads, heads.f_out = H, f_out
+            # |elu(v)| <= max(|v|, 1)
+            heads.fused_amax = None if pre_bound is None else torch.clamp(pre_bound * 1.001, min=1.0).reshape(1)
+            heads.pre_elu = None if concat else [fused[:, h * f_out:(h + 1) * f_out] for h in range(H)]
+            e_list = [edge_e[h].unsqueeze(1) for h in range(H)]
 
     aux_out = None
     if aux_indices is not None:
@@ -426,8 +480,21 @@ class FuseLayer(nn.Module):
             if self.residue_dim != 0:
                 self.fuse2 = nn.Linear(self.residue_dim, self.nfeat)
 
+    def accepts_planes(self):
+        """True when forward() consumes HeadList.planes directly (plain Linear on the concatenated heads, no residue
+        columns, a width the plane GEMM tiles): DISGAT._run then asks disga_heads not to write the fp32 head buffer."""
+        return (self.args.residue_type == 0 and self.residue_dim == 0 and self.fuse.weight.is_cuda
+                and ops_gemm.planes_ok(self.fuse.in_features, self.fuse.out_features))
+
     def forward(self, feature_list, residue=None):
+        planes = getattr(feature_list, "planes", None)
+        if planes is not None and self.accepts_planes() and not torch.is_grad_enabled():
+            act = ops_gemm.ACT_NONE if self.args.fuse_no_relu else ops_gemm.ACT_LEAKY
+            ws = _memo([self], "fuse_rm", lambda: ops_gemm.presplit_rm(self.fuse.weight.t()))
+            return ops_gemm.linear_planes(planes, ws, self.fuse.out_features, self.fuse.bias, None, act, 0.01)[0]
         features = getattr(feature_list, "fused", None)
+        if features is None and planes is not None:
+            features = planes.to_f32()
         if features is None:
             features = torch.cat(list(feature_list), dim=-1)
         use_res = self.residue_dim != 0 and residue is not None

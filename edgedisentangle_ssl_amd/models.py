@@ -43,34 +43,43 @@ class DISGAT(nn.Module):
 
     # The five entry points of the reference share one two-layer loop (models.py:181-373);
     # `_run` is that loop, returning everything any of them needs.
-    def _run(self, x, adj, fusers, auxiliary_edges=None, head_ranges=None, scores_only_layer2=False):
+    def _run(self, x, adj, fusers, auxiliary_edges=None, head_ranges=None, scores_only_layer2=False, heads_f32=True):
+        """heads_f32=False: the caller reads the per-head outputs only through HeadList.planes / .fused (get_em, the
+        score entry points, DifHead's batched classifier) - a layer whose fuser takes planes then never writes the
+        fp32 [N, H*nhid] head buffer on a no-graph forward."""
         if not isinstance(fusers, list):
             fusers = [fusers]
+        fu1 = self.fuser1 if not self.is_specific[0] else fusers[0]
+        fu2 = self.fuser2 if not self.is_specific[1] else fusers[1]
+
+        def planes_only(fuser):
+            return (not heads_f32 and not torch.is_grad_enabled() and isinstance(fuser, FuseLayer) and fuser.accepts_planes())
+
         x = F.dropout(x, self.dropout, training=self.training)
-        h1, adj1, aux1 = disga_heads(self.attentions1, x, adj, auxiliary_edges, head_ranges)
-        f1 = self.fuser1(h1, x) if not self.is_specific[0] else fusers[0](h1, x)
+        h1, adj1, aux1 = disga_heads(self.attentions1, x, adj, auxiliary_edges, head_ranges, heads_planes=planes_only(fu1))
+        f1 = fu1(h1, x)
         feature_1 = F.dropout(f1, self.dropout, training=self.training)
         h2, adj2, aux2 = disga_heads(self.attentions2, feature_1, adj, auxiliary_edges, head_ranges,
-                                     aux_only=scores_only_layer2)
+                                     aux_only=scores_only_layer2, heads_planes=planes_only(fu2))
         if scores_only_layer2:
             return dict(x=x, feature_1=feature_1, x2=None, heads=(h1, None), adjs=(adj1, None), aux=(aux1, aux2))
-        f2 = self.fuser2(h2, feature_1) if not self.is_specific[1] else fusers[1](h2, feature_1)
+        f2 = fu2(h2, feature_1)
         return dict(x=x, feature_1=feature_1, x2=f2, heads=(h1, h2), adjs=(adj1, adj2), aux=(aux1, aux2))
 
     def forward(self, x, adj, fusers):                                   # models.py:181-214
-        return F.log_softmax(self._run(x, adj, fusers)["x2"], dim=1)
+        return F.log_softmax(self._run(x, adj, fusers, heads_f32=False)["x2"], dim=1)
 
     def get_em(self, x, adj, fusers):                                    # models.py:217-252
-        r = self._run(x, adj, fusers)
+        r = self._run(x, adj, fusers, heads_f32=False)
         feature_2 = F.dropout(r["x2"], self.dropout, training=self.training)
         return [r["feature_1"], feature_2]
 
     def get_adjs(self, x, adj, fusers):                                  # models.py:254-288
-        r = self._run(x, adj, fusers)
+        r = self._run(x, adj, fusers, heads_f32=False)
         return [r["adjs"][0], r["adjs"][1]]
 
     def predict_adjs_sparse(self, x, adj, fusers, auxiliary_edges, head_ranges=None):   # models.py:290-330
-        r = self._run(x, adj, fusers, auxiliary_edges, head_ranges, scores_only_layer2=self.skip_unused)
+        r = self._run(x, adj, fusers, auxiliary_edges, head_ranges, scores_only_layer2=self.skip_unused, heads_f32=False)
         return [r["aux"][0], r["aux"][1]]
 
     def get_edge_em(self, x, adj, fusers):                               # models.py:333-373

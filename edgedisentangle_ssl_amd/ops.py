@@ -87,13 +87,15 @@ def _row_major(t, name):
 
 
 def edge_forward(graph: CSRGraph, att, H, F_in, F_out, x, rowop, colop, a, sage_div, drop=(0.0, 0), need_den=True,
-                 sign=None, e_in=None):
+                 sign=None, e_in=None, z_bound=None):
     """Launch disgat_edge_fwd (+ disgat_edge_combine for split rows).
 
     x [N, >=F_in] (row stride % 4 == 0), rowop/colop 2-D views with unit inner
     stride, a [H*F_out] or None; drop = (p, seed) of the attention dropout; sign: optional
     sign_record(...) buffer the att-3 kernel fills; e_in: optional contiguous [H,E] partial scores added before the
-    sigmoid.  Returns Z [N,H,F_in], edge_e [H,E], den [N,2,H].
+    sigmoid.  z_bound: optional device scalar >= max |Z|: Z is then returned as ops_gemm.Planes (the two fp16 planes the
+    f16x3 projection GEMM consumes, [N,H,F_in] each) instead of an fp32 tensor.
+    Returns Z [N,H,F_in], edge_e [H,E], den [N,2,H].
     """
     if e_in is not None:
         _check(e_in, "e_in")
@@ -105,7 +107,12 @@ def edge_forward(graph: CSRGraph, att, H, F_in, F_out, x, rowop, colop, a, sage_
     n, e = graph.n, graph.nnz
     dev = x.device
     wi = graph.work_items(CHUNK[att])
-    z = torch.empty((n, H, F_in), dtype=torch.float32, device=dev)
+    z = zh = zl = None
+    if z_bound is None:
+        z = torch.empty((n, H, F_in), dtype=torch.float32, device=dev)
+    else:
+        zh = torch.empty((n, H, F_in), dtype=torch.int16, device=dev)
+        zl = torch.empty_like(zh)
     edge_e = torch.empty((H, e), dtype=torch.float32, device=dev)
     den = torch.empty((n, 2, H), dtype=torch.float32, device=dev) if need_den else None
     part_z = part_den = None
@@ -117,10 +124,13 @@ def edge_forward(graph: CSRGraph, att, H, F_in, F_out, x, rowop, colop, a, sage_
             att, _ptr(wi.items), wi.n_items, _ptr(graph.col), e, n, H, F_in, F_out,
               _ptr(x), x.stride(0), _ptr(rowop), rowop.stride(0), _ptr(colop), 0 if colop is None else colop.stride(0),
               _ptr(a), _ptr(z), _ptr(edge_e), _ptr(den), _ptr(part_z), _ptr(part_den), int(bool(sage_div)),
-              float(drop[0]), int(drop[1]), _ptr(sign), _ptr(e_in), st)
+              float(drop[0]), int(drop[1]), _ptr(sign), _ptr(e_in), _ptr(zh), _ptr(zl), _ptr(z_bound), st)
     if wi.n_split:
         _lib.call("disgat_edge_combine", _ptr(wi.split_rows), _ptr(wi.split_ptr), wi.n_split, H, F_in,
-                  _ptr(part_z), _ptr(part_den), _ptr(z), _ptr(den), int(bool(sage_div)), st)
+                  _ptr(part_z), _ptr(part_den), _ptr(z), _ptr(den), int(bool(sage_div)), _ptr(zh), _ptr(zl), _ptr(z_bound), st)
+    if z_bound is not None:
+        from .ops_gemm import Planes
+        z = Planes(zh, zl, z_bound)
     return z, edge_e, den
 
 

@@ -122,8 +122,9 @@ class Planes:
 
 
 def planes_ok(k, n):
-    """Shapes disgat_gemm_planes takes (its tiling: 256 output columns per step, 32-deep k-steps)."""
-    return mode() == "f16x3" and n % 256 == 0 and k % 32 == 0 and k >= 64
+    """Shapes disgat_gemm_planes takes (its tiling: 256 output columns per step, 32-deep k-steps).  DISGAT_PLANES=0
+    switches the plane-operand chain off (same-box A/B against the fp32-operand kernels)."""
+    return mode() == "f16x3" and os.environ.get("DISGAT_PLANES", "1") != "0" and n % 256 == 0 and k % 32 == 0 and k >= 64
 
 
 def split_planes(x, bound=None):

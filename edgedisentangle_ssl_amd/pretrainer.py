@@ -307,7 +307,7 @@ class DifHeadTrainer(Trainer):
         reference builds per head (models.py:347, 365) are never materialised here; get_edge_em()
         still returns them for callers that want them."""
         feature, adj = data
-        r = self.models[0]._run(feature, adj, [self.fuse1, self.fuse2])
+        r = self.models[0]._run(feature, adj, [self.fuse1, self.fuse2], heads_f32=False)
         g = graph_of(adj)
         sharded = isinstance(g, parallel.DistGraph) and g.world > 1
         loss = None
@@ -315,17 +315,29 @@ class DifHeadTrainer(Trainer):
             classifier = self.classifier1 if layer == 0 else self.classifier2
             mods = list(classifier.model)
             fused = getattr(heads, "fused", None)
+            planes = getattr(heads, "planes", None)
+            nh, fo = getattr(heads, "n_heads", 0) or len(heads), getattr(heads, "f_out", 0) or heads[0].shape[1]
+            batched = (len(mods) >= 3 and isinstance(mods[0], torch.nn.Linear) and isinstance(mods[1], torch.nn.LeakyReLU)
+                       and (planes is not None or (fused is not None and fused.shape[1] == nh * fo)))
+            if fused is None and planes is not None and not (batched and not torch.is_grad_enabled()
+                                                             and ops_gemm.planes_ok(fo, mods[0].out_features)):
+                fused = planes.to_f32()            # a classifier shape the plane GEMM does not tile: fp32 heads after all
+                heads = [fused[:, h * fo:(h + 1) * fo] for h in range(nh)]
             if len(mods) < 3 or not isinstance(mods[0], torch.nn.Linear):     # cls_layer == 1: no shared part
                 outs = [classifier(torch.cat((inp, h), dim=-1), cls=True) for h in heads]
-            elif fused is not None and isinstance(mods[1], torch.nn.LeakyReLU) and fused.shape[1] == len(heads) * heads[0].shape[1]:
+            elif batched:
                 # all heads in one batched GEMM on the fused [N, H*nhid] buffer: no per-head slices in the autograd
                 # graph (each slice's backward zero-fills and re-adds a full [N, H*nhid] gradient)
                 lin = mods[0]
-                f_in, nh, fo = inp.shape[1], len(heads), heads[0].shape[1]
+                f_in = inp.shape[1]
                 shared = ops_gemm.linear(inp, lin.weight[:, :f_in].t(), lin.bias)
                 w_h = lin.weight[:, f_in:].t().unsqueeze(0).expand(nh, fo, -1)
-                t = ops_gemm.linear(fused.view(-1, nh, fo).permute(1, 0, 2), w_h, None, shared, ops_gemm.ACT_LEAKY,
-                                    mods[1].negative_slope, a_amax=getattr(heads, "fused_amax", None))   # [N, H*hidden]
+                if fused is None:      # no-graph forward: the head buffer exists only as the GEMM's operand planes
+                    t = ops_gemm.linear_planes(planes.view_heads(nh), ops_gemm.presplit_rm(w_h), lin.out_features, None, shared,
+                                               ops_gemm.ACT_LEAKY, mods[1].negative_slope)[0]
+                else:
+                    t = ops_gemm.linear(fused.view(-1, nh, fo).permute(1, 0, 2), w_h, None, shared, ops_gemm.ACT_LEAKY,
+                                        mods[1].negative_slope, a_amax=getattr(heads, "fused_amax", None))   # [N, H*hidden]
                 t = t.view(t.shape[0] * nh, -1)
                 for m in mods[2:]:
                     t = m(t)

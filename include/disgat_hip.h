@@ -79,7 +79,10 @@ const char* disgat_last_error(void);
 
 /* Fused score -> sigmoid -> row softmax -> aggregation for all H heads of one layer.
  * e_in (or NULL): [H][E] partial scores added before the sigmoid - a head wider than one launch's 1024 features is
- * scored in feature slices (disgat_aux_score on the edge list for all but the last slice); edge_e receives the total. */
+ * scored in feature slices (disgat_aux_score on the edge list for all but the last slice); edge_e receives the total.
+ * Z_hi / Z_lo / z_bound (or all NULL): write the aggregate as the two fp16 planes of disgat_gemm_planes' A operand
+ * ([N][H][F_in] halfs each, hi and lo of Z * s with s from *z_bound >= max |Z|) INSTEAD of fp32 Z (which may then be
+ * NULL): the per-head projection that consumes Z then splits nothing. */
 int disgat_edge_fwd(int att, const int32_t* items, int n_items, const int32_t* col, int64_t E,
                     int N, int H, int F_in, int F_out,
                     const float* x, int ldx,
@@ -89,12 +92,14 @@ int disgat_edge_fwd(int att, const int32_t* items, int n_items, const int32_t* c
                     float* Z, float* edge_e, float* den,
                     float* part_z, float* part_den,
                     int sage_div, float drop_p, uint64_t drop_seed,
-                    uint32_t* sign_bits, const float* e_in, disgat_stream_t stream);
+                    uint32_t* sign_bits, const float* e_in,
+                    uint16_t* Z_hi, uint16_t* Z_lo, const float* z_bound, disgat_stream_t stream);
 
 /* Sums the partial records of split rows (in chunk order: deterministic) and normalises. */
 int disgat_edge_combine(const int32_t* split_rows, const int32_t* split_ptr, int n_split,
                         int H, int F_in, const float* part_z, const float* part_den,
-                        float* Z, float* den, int sage_div, disgat_stream_t stream);
+                        float* Z, float* den, int sage_div,
+                        uint16_t* Z_hi, uint16_t* Z_lo, const float* z_bound, disgat_stream_t stream);
 
 /* Raw scores of M arbitrary node pairs, heads [h_lo, h_hi) only; out is [H][M]. */
 int disgat_aux_score(int att, const int64_t* pair_rows, const int64_t* pair_cols, int64_t M,
