@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--att", type=int, default=3)
     ap.add_argument("--gnn_type", default="AT")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-nodes", type=int, default=16384)
+    ap.add_argument("--cpu-nodes", type=int, default=4096)
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary measurements (T_fwd, skip-unused T_iter, exact-operand GEMM T_iter, training step)")
     ap.add_argument("--fwd-only", action="store_true", help="time one get_em (T_fwd) instead of T_iter")
@@ -233,16 +233,27 @@ def usable_cores():
     return max(1, min(n, int(os.environ.get("DISGAT_CPU_THREADS", "16"))))
 
 
-def cpu_baseline(o, feat=None, gnn=None, one_run=False):
-    """The oracle (CPU restatement of the reference's op sequence: kind "port") timed on this box's
-    host cores on a bounded sample of the same workload: same generator, feature width, heads and
-    attention type, fewer nodes (--cpu-nodes; the per-edge cost of the CPU path is flat in N)."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(o, feat=None, gnn=None, n=None, warm=1, runs=2):
+    """The oracle (CPU restatement of the reference's op sequence: kind "port") timed on this box's host cores on a
+    bounded sample of the same workload: same generator, feature width, heads and attention type, fewer nodes (the
+    per-edge cost of the CPU path is flat in N: the 4x larger second sample in the bench line shows it).  SURVEY 8(d)
+    protocol: `warm` untimed run(s), then the mean of `runs` timed ones."""
     from oracle import disgat_oracle as orc
     from edgedisentangle_ssl_amd import DISGAT, MLP, FuseLayer, synth
     torch.set_num_threads(usable_cores())
     feat = o.feat if feat is None else feat
     gnn = o.gnn_type if gnn is None else gnn
-    n = o.cpu_nodes
+    n = o.cpu_nodes if n is None else n
     e = n * (o.edges // o.nodes)
     cpu = torch.device("cpu")
     graph = synth.powerlaw_graph(n, e, cpu)
@@ -272,23 +283,19 @@ def cpu_baseline(o, feat=None, gnn=None, one_run=False):
             l3 = orc.dif_head_loss(r["edge_em"], c1, c2)
         return float(l1 + l2 + l3)
 
-    print(f"[bench] cpu_baseline: oracle on N={n} nnz={graph.nnz} F={feat} {gnn}, {torch.get_num_threads()} threads ...",
-          file=sys.stderr, flush=True)
+    print(f"[bench] cpu_baseline: oracle on N={n} nnz={graph.nnz} F={feat} {gnn}, {torch.get_num_threads()} threads, "
+          f"{warm} warm-up + {runs} timed ...", file=sys.stderr, flush=True)
+    for _ in range(warm):
+        step()
     t0 = time.time()
-    step()
-    t1 = time.time() - t0
-    print(f"[bench] cpu_baseline first step {t1:.1f}s", file=sys.stderr, flush=True)
-    if one_run or t1 > 25:     # keep the whole bench within a few minutes: report the one (cold) run
-        reps, dt = 0, t1
-    else:
-        reps = 1 if t1 > 12 else 2
-        t0 = time.time()
-        for _ in range(reps):
-            step()
-        dt = (time.time() - t0) / reps
+    for _ in range(runs):
+        step()
+    dt = (time.time() - t0) / runs
+    print(f"[bench] cpu_baseline {dt:.1f}s per T_iter", file=sys.stderr, flush=True)
     return {"value": graph.nnz / dt, "unit": "edges/s", "cores": torch.get_num_threads(), "kind": "port",
+            "cpu_model": cpu_model(),
             "sample": f"same generator/config, N={n} nnz={graph.nnz} F={feat} H={o.heads} att={o.att} "
-                      f"gnn={gnn}, T_iter {dt:.2f}s, " + (f"mean of {reps} run(s) after 1 warm-up" if reps else "single cold run")}
+                      f"gnn={gnn}, T_iter {dt:.2f}s, mean of {runs} run(s) after {warm} warm-up(s)"}
 
 
 def secondary_measurements(o, enc, trainers, graph, x, lists):
@@ -425,15 +432,31 @@ def launch_ranks(o):
         env.setdefault("OMP_NUM_THREADS", "4")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True))
-    out, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    for p in procs[1:]:
-        try:
-            rc = max(rc, abs(p.wait(timeout=120 if rc == 0 else 5)))
-        except subprocess.TimeoutExpired:       # a rank outlived rank 0 (rank 0 failed before a collective): end it
-            p.kill()
-            p.wait()
-            rc = rc or 1
+    # Watch ALL ranks: if any of them dies (missing GPU, OOM, build error) before or inside a collective, rank 0 would
+    # sit in RCCL until the process-group timeout (~10 min) and the driver would see a hang.  Rank 0's stdout is drained
+    # by a thread so that polling never blocks on the pipe; the first non-zero exit ends the others.
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    rc = 0
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [c for c in codes if c not in (None, 0)]
+        if bad:
+            rc = abs(bad[0]) or 1
+            time.sleep(1.0)                     # let a rank that is failing on its own finish its traceback
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            break
+        if all(c == 0 for c in codes):
+            break
+        time.sleep(0.2)
+    for p in procs:
+        p.wait()
+    reader.join(timeout=10)
+    out = "".join(c for c in chunks if c)
     for line in out.splitlines():          # stdout carries the ONE JSON line; anything else a library printed -> stderr
         (sys.stdout if line.startswith("{") else sys.stderr).write(line + "\n")
     sys.stdout.flush()
@@ -454,6 +477,8 @@ def main():
         # launcher self-test (tests/test_bench_launcher.py, no GPU): rendezvous over gloo, one collective, and the
         # line rank 0 prints takes n_gpus from the process group - everything launch_ranks() is responsible for
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if os.environ.get("DISGAT_BENCH_PROBE_DIE_EARLY_RANK") == str(rank):
+            raise SystemExit(4)                 # a rank that never reaches the rendezvous: the others would wait for it
         dist.init_process_group("gloo")
         t = torch.tensor([float(dist.get_rank())])
         dist.all_reduce(t)
@@ -558,9 +583,13 @@ def main():
         secondary = secondary_measurements(o, enc, trainers, graph, x, lists)
     cpu = None
     if not o.no_cpu_baseline and world == 1:          # rank 0, N=1 only (bench contract)
+        # ~2.5 min in all on the box's 16-core share: N = 4 096 (1 warm-up + 2 timed, ~18 s each) is the reported
+        # value; one run at 4x the size shows the per-edge rate is flat in N; BASELINE configs[2]'s shape beside it
         cpu = cpu_baseline(o)
-        if (o.feat, o.gnn_type) != (128, "SAGE"):      # BASELINE configs[2]'s shape (F = 128, SAGE) beside it, one run
-            c3 = cpu_baseline(o, feat=128, gnn="SAGE", one_run=True)
+        big = cpu_baseline(o, n=4 * o.cpu_nodes, warm=0, runs=1)
+        cpu["at_4x_nodes"] = {k: big[k] for k in ("value", "unit", "sample")}
+        if (o.feat, o.gnn_type) != (128, "SAGE"):
+            c3 = cpu_baseline(o, feat=128, gnn="SAGE", warm=0, runs=1)
             cpu["configs2_F128_SAGE"] = {k: c3[k] for k in ("value", "unit", "sample")}
     what = "T_fwd(get_em)" if o.fwd_only else "T_iter(SupEdge+DisEdge+DifHead fwd+loss)"
     if o.skip_unused and not o.fwd_only:

@@ -112,7 +112,7 @@ class CSRGraph:
         """The edge list as a pair list for the aux scorer (built once; in range by construction)."""
         if self._pairs is None:
             self._pairs = self.indices().contiguous()
-            self._pairs._disgat_in_range = True
+            self._pairs._disgat_checked = (int(self.n), int(getattr(self, "n_cols", self.n)), self._pairs._version)
         return self._pairs
 
     # ------------------------------------------------------------------ work items

@@ -196,7 +196,7 @@ def _pack_score_operands(layers, x, x_all, att, H, Hp, f_in, f_out, fp, am=None,
         zero = [x.new_zeros(f_in)] * (Hp - H)
         w1 = torch.stack([l.W @ l.a[:f_out, 0] for l in layers] + zero, dim=1)     # [F_in, Hp]
         w2 = torch.stack([l.W @ l.a[f_out:, 0] for l in layers] + zero, dim=1)
-        return x @ w1, x_all @ w2, None                                            # N = Hp: too narrow for the MFMA tile
+        return x @ w1, parallel.finish(x_all) @ w2, None                           # N = Hp: too narrow for the MFMA tile
     if att == 4:
         # att 2 as the reference writes it (layers.py:362-365): h = x W per head, e = <h[r], h[c]>.  One operand table
         # serves both sides (column ids index the gathered x_all; unsharded, x_all is x and the GEMM runs once).
@@ -205,9 +205,11 @@ def _pack_score_operands(layers, x, x_all, att, H, Hp, f_in, f_out, fp, am=None,
             return wc, ops_gemm.presplit(wc)
 
         wc, sc = _memo(layers, ("att4", fp, Hp, c0, c1), pack4)
-        hcol = ops_gemm.linear(x_all, wc, a_amax=am, w_split=sc)
-        hrow = hcol if x_all is x else ops_gemm.linear(x, wc, a_amax=am, w_split=sc)
-        return hrow, hcol, None
+        if x_all is x:
+            hcol = ops_gemm.linear(x_all, wc, a_amax=am, w_split=sc)
+            return hcol, hcol, None
+        hrow = ops_gemm.linear(x, wc, a_amax=am, w_split=sc)                      # own rows first: the gather may still be arriving
+        return hrow, _col_operand(x_all, wc, am, sc), None
     if att == 2:
         f_in_p = (f_in + 3) // 4 * 4
         ms = [F.pad(l.W @ l.W.t(), (0, f_in_p - f_in)) for l in layers]
@@ -221,7 +223,16 @@ def _pack_score_operands(layers, x, x_all, att, H, Hp, f_in, f_out, fp, am=None,
         return wt, wb, a_vec.contiguous(), ops_gemm.presplit(wt), ops_gemm.presplit(wb)
 
     wt, wb, a_vec, st, sb = _memo(layers, ("att3", fp, Hp, c0, c1), pack3)
-    return ops_gemm.linear(x, wt, a_amax=am, w_split=st), ops_gemm.linear(x_all, wb, a_amax=am, w_split=sb), a_vec
+    p_row = ops_gemm.linear(x, wt, a_amax=am, w_split=st)         # own rows: runs while the all-gather's slices are on the links
+    return p_row, _col_operand(x_all, wb, am, sb), a_vec
+
+
+def _col_operand(x_all, w, am, w_split):
+    """x_all @ w for the column-side score operand; a gathered table still arriving (parallel.exchange(pipelined=True))
+    is consumed slice by slice as it lands."""
+    if parallel.pending_of(x_all) is not None:
+        return parallel.project_gathered(x_all, w, am, w_split)
+    return ops_gemm.linear(x_all, w, a_amax=am, w_split=w_split)
 
 
 def _no_graph(layers, x):
@@ -283,19 +294,25 @@ def disga_heads(layers, x, adj, aux_indices=None, head_ranges=None, aux_only=Fal
     tile = min(512, 256 * max(1, 16 // Hk))
     assert not (att == 2 and f_in_p > tile), "att 2 wider than its register tile is routed to the projected form above"
     # sharded: one exchange per layer - all rows, or only the referenced ones for edge-only passes
-    x_all, graph = parallel.exchange(x, graph, edge_only=aux_indices is None)
-    xg = x_all if (f_in_p == f_in and x_all.is_contiguous()) else F.pad(x_all, (0, f_in_p - f_in)).contiguous()
+    x_all, graph = parallel.exchange(x, graph, edge_only=aux_indices is None, pipelined=True)
 
     # Scale inputs of the f16x3 GEMMs.  max |x| is measured once (1 pass over the layer input); the two 8x larger
     # operands get analytic upper bounds instead of their own pass: every Z row is a non-negative combination of x
     # rows with total weight <= 1/(1-p) (softmax weights, attention dropout rescaling; SageConv only divides further),
     # and a GEMM output is bounded by its input bound times the weight's largest column abs-sum.  A loose bound costs
     # no precision (the scheme is exact to 2^-23 per element down to 2^-27 of the scale), only range.
-    am_x = ops_gemm.amax_for(x_all)
+    if parallel.pending_of(x_all) is not None:      # the gathered table is still arriving: max over the ranks' own rows instead
+        am_x = ops_gemm.amax_for(x)
+        if am_x is not None:
+            parallel.all_reduce_max(am_x, graph)
+    else:
+        am_x = ops_gemm.amax_for(x_all)
     z_bound = None if am_x is None else am_x * (1.001 / (1.0 - drop[0]))
     slice_ops = [_pack_score_operands(layers, x, x_all, att, H, Hp, f_in, f_out, fp, am_x,
                                       cols=None if len(f_slices) == 1 else sl) for sl in f_slices]
     rowop, colop, a_vec = slice_ops[-1]
+    parallel.finish(x_all)                          # the edge pass / aux scorer gather rows of the whole table
+    xg = x_all if (f_in_p == f_in and x_all.is_contiguous()) else F.pad(x_all, (0, f_in_p - f_in)).contiguous()
     # per-head operand width inside a row of rowop / colop (att 1: one scalar, att 2: F_in_p, att 3: fp)
     w_row = {1: 1, 2: f_in_p, 3: fp, 4: fp}[att]
 

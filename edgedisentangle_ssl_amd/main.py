@@ -42,6 +42,20 @@ def load_model(encoder, args, root="."):
     return path
 
 
+def reseed_rank(seed, rank):
+    """Sharded runs: parameter initialisation and utils.split() must draw the SAME numbers on every rank (replicated
+    parameters, global index sets) and have done so by now; from here on every rank needs its OWN streams - the pair
+    sampler (device randint / randperm + the host binomial), the input dropout and the in-kernel attention-dropout seed
+    (taken from torch's CPU generator, layers.disga_heads) would otherwise repeat the same (local row, column)
+    negatives and the same per-edge mask on every equal-size shard, and the union over ranks would not be the unsharded
+    Bernoulli(3 rho) sample sampling.py promises."""
+    s = int(seed) + 1000003 * (int(rank) + 1)
+    random.seed(s)
+    np.random.seed(s % (2 ** 32))
+    torch.manual_seed(s)
+    torch.cuda.manual_seed(s)
+
+
 def run(argv=None, log=print):
     parser = get_parser()
     parser.add_argument("--data_root", type=str, default="data")
@@ -129,6 +143,8 @@ def run(argv=None, log=print):
             raise SystemExit("downstream 'Edge' is declared unfinished by the reference (README.md:23)")
         down.append(trainer.ClsTrainer(args, encoder, labels, args.down_weight[0]))
 
+    if world > 1:
+        reseed_rank(args.seed, rank)
     history = []
     t0 = time.time()
     for epoch in range(args.epochs):                                      # main.py:270-360

@@ -141,13 +141,23 @@ def edge_forward(graph: CSRGraph, att, H, F_in, F_out, x, rowop, colop, a, sage_
 CHECK_INDICES = True
 
 
-def mark_checked(pairs):
-    pairs._disgat_in_range = True
+def mark_checked(pairs, n_rows=None, n_cols=None):
+    """Record that `pairs` lies in [0, n_rows) x [0, n_cols) (None = "any table", for lists built from the graph's own
+    ids) at its current version: check_pairs skips the device round trip for the same or a larger table while the
+    tensor is not modified in place."""
+    pairs._disgat_checked = (float("inf") if n_rows is None else int(n_rows), float("inf") if n_cols is None else int(n_cols),
+                             pairs._version)
     return pairs
 
 
 def check_pairs(pairs, n_rows, n_cols):
-    if not CHECK_INDICES or getattr(pairs, "_disgat_in_range", False) or pairs.shape[1] == 0:
+    """Range check of a pair list against the operand tables it will index.  The verdict is remembered ON the tensor
+    together with the bounds it was checked against and the tensor's version counter: a list checked for a full graph
+    is re-checked when it meets a smaller table (a row shard, a halo-compact table) or after an in-place edit."""
+    if not CHECK_INDICES or pairs.shape[1] == 0:
+        return
+    seen = getattr(pairs, "_disgat_checked", None)
+    if seen is not None and seen[2] == pairs._version and seen[0] <= n_rows and seen[1] <= n_cols:
         return
     r_lo, r_hi = torch.aminmax(pairs[0])
     c_lo, c_hi = torch.aminmax(pairs[1])
@@ -156,7 +166,7 @@ def check_pairs(pairs, n_rows, n_cols):
         raise RuntimeError(f"auxiliary pair list out of range: rows in [{r_lo},{r_hi}] (must be < {n_rows}), "
                            f"columns in [{c_lo},{c_hi}] (must be < {n_cols})")
     try:
-        pairs._disgat_in_range = True
+        pairs._disgat_checked = (int(r_hi) + 1, int(c_hi) + 1, pairs._version)      # the tightest table this list fits
     except AttributeError:
         pass
 

@@ -185,13 +185,17 @@ def linear_planes(ap, w_rm, n, bias=None, init=None, act=ACT_NONE, slope=0.01, w
     return out, (None if oh is None else Planes(oh, ol, out_bound))
 
 
-def _forward(a, w, bias, init, act, slope, a_amax=None, w_split=None):
+def _forward(a, w, bias, init, act, slope, a_amax=None, w_split=None, out=None):
+    """out: optional preallocated 2-D result (row-contiguous view, e.g. a row block of a larger table) to write into."""
     batched = a.dim() == 3
     if batched:
         hb, m, k = a.shape
         n = w.shape[2]
     else:
         hb, (m, k), n = 1, a.shape, w.shape[1]
+    out_arg = out
+    if out_arg is not None and (tuple(out_arg.shape) != (m, hb * n) or out_arg.stride(-1) != 1 or out_arg.dtype != torch.float32):
+        raise RuntimeError("ops_gemm: `out` must be a float32 [M, N] view with unit inner stride")
     if not _kernel_ok(a, k, n):
         if batched:
             out3 = torch.bmm(a, w)
@@ -204,8 +208,12 @@ def _forward(a, w, bias, init, act, slope, a_amax=None, w_split=None):
                 out = out + bias
         if init is not None:
             out = out + (init.repeat(1, hb) if batched and init.shape == (m, n) and hb > 1 else init)
-        return _apply_act(out, act, slope)
-    out = torch.empty((m, hb * n), dtype=torch.float32, device=a.device)
+        res = _apply_act(out, act, slope)
+        if out_arg is not None:
+            out_arg.copy_(res)
+            return out_arg
+        return res
+    out = out_arg if out_arg is not None else torch.empty((m, hb * n), dtype=torch.float32, device=a.device)
     init_bs = n if batched else 0
     if init is not None and batched and init.shape == (m, n) and init.stride(-1) == 1:
         init_bs = 0                                  # one [M,N] init shared by all heads: batch stride 0
@@ -266,6 +274,22 @@ def _weight_grad(a, g, a_amax, g_amax):
               ops._stream())
     out = part.sum(1) if splits > 1 else part[:, 0]
     return out if batched else out[0]
+
+
+def linear_backward(a, w, g, a_amax=None, need_a=True, need_w=True):
+    """(grad a, grad w) of a @ w (2-D, no bias / activation) on the f16x3 kernels where their tiling allows."""
+    g_am = None
+    if mode() == "f16x3" and g.is_cuda and g.dim() == 2 and g.is_contiguous() and g.shape[1] % 4 == 0 and g.data_ptr() % 16 == 0:
+        g_am = amax(g)
+    ga = gw = None
+    if need_a:
+        ga = _forward(g, w.t(), None, None, ACT_NONE, 0.0, g_am)
+    if need_w:
+        if g_am is not None and _tn_ok(a, g, a.shape[1], g.shape[1]):
+            gw = _weight_grad(a, g, a_amax if a_amax is not None else amax(a), g_am)
+        else:
+            gw = a.t() @ g
+    return ga, gw
 
 
 class _Linear(torch.autograd.Function):

@@ -64,35 +64,115 @@ class DistGraph(CSRGraph):
                          (graph.row[e0:e1] - lo).contiguous(), graph.n, lo, counts, group)
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# Pipelined all-gather ("overlap with the row-side GEMM").  The layer input is gathered in EXCHANGE_SLICES
+# asynchronous collectives - slice j carries rows [j/S, (j+1)/S) of EVERY rank's range, so each collective uses all
+# links of the xGMI mesh like the one big all-gather did (a per-peer split would light one source's links at a time) -
+# and the consumers start on what has arrived: the rank's own rows need no wait at all (P = x_local W_top and the
+# own-row block of Q run while slice 0 is on the links), then Q[rows of slice j] = x_all[rows of slice j] W_bot as each
+# slice lands (layers._pack_score_operands -> project_gathered).  With the nccl (= RCCL) backend an async collective
+# runs on the process group's own stream and work.wait() only makes the compute stream wait for it: the host never
+# blocks.  Ragged (nnz-balanced) ranges: every slice is padded to its longest member - one padded
+# all_gather_into_tensor per slice, no tensor lists, no torch.cat.
+def exchange_slices():
+    import os
+    return max(1, int(os.environ.get("DISGAT_EXCHANGE_SLICES", "4")))
+
+
+_PENDING = {}       # data_ptr of an x_all still being filled -> its PendingGather
+
+
+class PendingGather:
+    def __init__(self, x_local, counts, group, n_slices):
+        world, rank = len(counts), dist.get_rank(group)
+        self.counts, self.rank, self.group = counts, rank, group
+        self.offsets = [0]
+        for c in counts:
+            self.offsets.append(self.offsets[-1] + c)
+        feat = tuple(x_local.shape[1:])
+        self.x_all = x_local.new_empty((self.offsets[-1],) + feat)
+        self.x_all[self.offsets[rank]: self.offsets[rank + 1]] = x_local              # own rows: valid at once
+        self.own = (self.offsets[rank], self.offsets[rank + 1])
+        self.slices = []
+        S = max(1, min(n_slices, max(counts) if counts else 1))
+        for j in range(S):
+            lo = [(c * j) // S for c in counts]
+            sz = [(c * (j + 1)) // S - l for c, l in zip(counts, lo)]
+            ms = max(sz)
+            if ms == 0:
+                continue
+            inp = x_local[lo[rank]: lo[rank] + sz[rank]]
+            if sz[rank] != ms:                                   # ragged: pad this rank's slice to the longest
+                pad = x_local.new_zeros((ms,) + feat)
+                pad[: sz[rank]] = inp
+                inp = pad
+            tmp = x_local.new_empty((world * ms,) + feat)
+            work = dist.all_gather_into_tensor(tmp, inp.contiguous(), group=group, async_op=True)
+            self.slices.append((work, tmp, ms, lo, sz))
+        self.next = 0
+        _PENDING[self.x_all.data_ptr()] = self
+
+    def wait_next(self):
+        """Wait (stream-level) for the next slice and copy the peers' rows into place.  Returns the global row ranges
+        [(lo, hi), ...] that became valid, or None when nothing is pending any more."""
+        if self.next >= len(self.slices):
+            _PENDING.pop(self.x_all.data_ptr(), None)
+            return None
+        work, tmp, ms, lo, sz = self.slices[self.next]
+        self.slices[self.next] = None
+        self.next += 1
+        work.wait()
+        ranges = []
+        for r, (l, n) in enumerate(zip(lo, sz)):
+            if r == self.rank or n == 0:
+                continue
+            g0 = self.offsets[r] + l
+            self.x_all[g0: g0 + n] = tmp[r * ms: r * ms + n]
+            ranges.append((g0, g0 + n))
+        if self.next >= len(self.slices):
+            _PENDING.pop(self.x_all.data_ptr(), None)
+        return ranges
+
+    def wait_all(self):
+        while self.wait_next() is not None:
+            pass
+
+
+def pending_of(x_all):
+    """The PendingGather still filling `x_all`, or None (unsharded / complete / halo table)."""
+    return _PENDING.get(x_all.data_ptr()) if torch.is_tensor(x_all) else None
+
+
+def finish(x_all):
+    """Make every row of a gathered table valid for the kernels enqueued after this call."""
+    pend = pending_of(x_all)
+    if pend is not None:
+        pend.wait_all()
+    return x_all
+
+
 class _AllGatherRows(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, counts, group):
+    def forward(ctx, x, counts, group, n_slices=1, leave_pending=False):
         ctx.counts, ctx.group = counts, group
-        world = len(counts)
-        rank = dist.get_rank(group)
-        if len(set(counts)) == 1:
-            out = x.new_empty((counts[0] * world,) + tuple(x.shape[1:]))
-            dist.all_gather_into_tensor(out, x.contiguous(), group=group)
-            return out
-        mx = max(counts)
-        pad = x.new_zeros((mx,) + tuple(x.shape[1:]))
-        pad[: counts[rank]] = x
-        bufs = [torch.empty_like(pad) for _ in range(world)]
-        dist.all_gather(bufs, pad, group=group)
-        return torch.cat([b[:c] for b, c in zip(bufs, counts)], 0)
+        pend = PendingGather(x, counts, group, n_slices)
+        if not leave_pending:
+            pend.wait_all()
+        return pend.x_all
 
     @staticmethod
     def backward(ctx, g):
         """Adjoint of the all-gather: every rank holds a gradient for ALL rows; the owner of a row range needs their
-        sum over ranks = one reduce-scatter (each rank receives 1/G of what an all-reduce would move)."""
+        sum over ranks = one reduce-scatter (each rank receives 1/G of what an all-reduce would move), ragged ranges
+        padded to the longest; asynchronous, the compute stream (not the host) waits for it."""
         counts, group = ctx.counts, ctx.group
         rank = dist.get_rank(group)
         world = len(counts)
         g = g.contiguous()
         if len(set(counts)) == 1:
             out = g.new_empty((counts[0],) + tuple(g.shape[1:]))
-            dist.reduce_scatter_tensor(out, g, group=group)
-            return out, None, None
+            dist.reduce_scatter_tensor(out, g, group=group, async_op=True).wait()
+            return out, None, None, None, None
         mx = max(counts)                          # ragged (nnz-balanced) ranges: pad every range to the longest
         pad = g.new_zeros((world, mx) + tuple(g.shape[1:]))
         off = 0
@@ -100,15 +180,56 @@ class _AllGatherRows(torch.autograd.Function):
             pad[r, :c] = g[off: off + c]
             off += c
         out = g.new_empty((mx,) + tuple(g.shape[1:]))
-        dist.reduce_scatter_tensor(out, pad.view((world * mx,) + tuple(g.shape[1:])), group=group)
-        return out[: counts[rank]], None, None
+        dist.reduce_scatter_tensor(out, pad.view((world * mx,) + tuple(g.shape[1:])), group=group, async_op=True).wait()
+        return out[: counts[rank]], None, None, None, None
+
+
+class _ProjectGathered(torch.autograd.Function):
+    """q = x_all @ w for a gathered table that may still be arriving: the rank's own rows first, then every slice's
+    rows as it lands - the redundant column-side GEMM of the sharded path runs under the links' time instead of
+    after it.  Backward = the plain linear backward (the all-gather's adjoint then reduce-scatters grad x_all)."""
+
+    @staticmethod
+    def forward(ctx, x_all, w, a_amax, w_split):
+        from . import ops_gemm
+        pend = pending_of(x_all)
+        q = x_all.new_empty((x_all.shape[0], w.shape[1]))
+
+        def block(lo, hi):
+            if hi > lo:
+                ops_gemm._forward(x_all[lo:hi], w, None, None, ops_gemm.ACT_NONE, 0.0, a_amax, w_split, out=q[lo:hi])
+
+        if pend is None:
+            block(0, x_all.shape[0])
+        else:
+            block(*pend.own)
+            while True:
+                ranges = pend.wait_next()
+                if ranges is None:
+                    break
+                for lo, hi in ranges:
+                    block(lo, hi)
+        ctx.save_for_backward(x_all, w)
+        ctx.a_amax = a_amax
+        return q
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import ops_gemm
+        x_all, w = ctx.saved_tensors
+        ga, gw = ops_gemm.linear_backward(x_all, w, g.contiguous(), ctx.a_amax, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return ga, gw, None, None
+
+
+def project_gathered(x_all, w, a_amax=None, w_split=None):
+    return _ProjectGathered.apply(x_all, w, a_amax, w_split)
 
 
 def all_gather_rows(x_local, graph):
     """[n_local,F] on every rank -> [n_global,F] (rank order = row order).  Identity when unsharded."""
     if not isinstance(graph, DistGraph) or graph.world == 1:
         return x_local
-    return _AllGatherRows.apply(x_local, graph.counts, graph.group)
+    return _AllGatherRows.apply(x_local, graph.counts, graph.group, exchange_slices(), False)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -206,10 +327,12 @@ def _static_key(x):
     return (x.data_ptr(), ver, tuple(x.shape))
 
 
-def exchange(x_local, graph, edge_only):
+def exchange(x_local, graph, edge_only, pipelined=False):
     """The per-layer exchange.  Returns (x_cols, graph_eff): the operand table column ids of `graph_eff`
     index.  Unsharded: (x_local, graph).  Sharded: the full all-gather (graph unchanged), or - for passes that score
-    no auxiliary pairs - the halo exchange with the compact re-indexed graph."""
+    no auxiliary pairs - the halo exchange with the compact re-indexed graph.
+    pipelined=True: the all-gather is returned while its slices are still on the links (pending_of(x_cols) is then
+    not None); the caller consumes it through project_gathered() / finish()."""
     if not isinstance(graph, DistGraph) or graph.world == 1:
         return x_local, graph
     import os
@@ -228,10 +351,10 @@ def exchange(x_local, graph, edge_only):
         hit = graph.__dict__.get("_static_gather")
         if hit is not None and hit[0] == key:
             return hit[1], graph
-        x_all = _AllGatherRows.apply(x_local, graph.counts, graph.group)
+        x_all = _AllGatherRows.apply(x_local, graph.counts, graph.group, exchange_slices(), False)
         graph._static_gather = (key, x_all.detach())
         return x_all, graph
-    return _AllGatherRows.apply(x_local, graph.counts, graph.group), graph
+    return _AllGatherRows.apply(x_local, graph.counts, graph.group, exchange_slices(), bool(pipelined)), graph
 
 
 def all_reduce_grads(modules, graph):
@@ -257,6 +380,12 @@ def all_reduce_grads(modules, graph):
             p.grad.copy_(g)
         elif any_rank > 0:                         # unused on every rank (e.g. the encoder's own fusers): stays None,
             p.grad = g.clone()                     # so the optimiser skips it exactly as in the unsharded run
+
+
+def all_reduce_max(t, graph):
+    if isinstance(graph, DistGraph) and graph.world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=graph.group)
+    return t
 
 
 def all_reduce_sum(t, graph):

@@ -64,7 +64,7 @@ def sample_pairs(n_rows, pos_flat, generator=None, n_cols=None, n_pos_global=Non
     labels = membership(flat, pos_flat)
     rows = torch.div(flat, n_cols, rounding_mode="floor")
     idx = torch.stack([rows, flat - rows * n_cols])
-    idx._disgat_in_range = True          # in [0, n_rows) x [0, n_cols) by construction: ops.check_pairs skips it
+    idx._disgat_checked = (int(n_rows), int(n_cols), idx._version)   # in range by construction (ops.check_pairs): no round trip
     return idx, labels
 
 

@@ -40,3 +40,13 @@ def test_under_torchrun_env_this_process_is_a_rank():
 def test_failing_rank_fails_the_launch():
     r = _run(["--gpus", "2"], {"DISGAT_BENCH_PROBE_FAIL_RANK": "1"})
     assert r.returncode != 0
+
+
+def test_rank_dying_before_the_rendezvous_ends_the_launch_promptly():
+    """A rank that exits before it joins the process group leaves the others waiting in the rendezvous (RCCL: in the
+    first collective, for the ~10 min process-group timeout); the launcher watches every rank and ends them."""
+    import time
+    t0 = time.time()
+    r = _run(["--gpus", "2"], {"DISGAT_BENCH_PROBE_DIE_EARLY_RANK": "1"})
+    assert r.returncode != 0
+    assert time.time() - t0 < 120

@@ -188,6 +188,22 @@ def test_launchers_reject_bad_arguments(dev):
             ops.aux_forward(3, 4, 16, 64, torch.tensor(bad, dtype=torch.int64, device=dev), n, x, p4, p4, p4[0].contiguous(), 0, 4)
     with pytest.raises(ValueError, match="out of range"):
         CSRGraph.from_index(torch.tensor([[0, 1], [1, n]], device=dev), n)
+    # the verdict is remembered with the bounds it holds for and the tensor's version: a checked list is checked again
+    # when it meets a smaller table, and after an in-place edit
+    ok = torch.tensor([[0, 3], [1, n - 1]], dtype=torch.int64, device=dev)
+    ops.check_pairs(ok, n, n)
+    assert ok._disgat_checked[:2] == (4, n)
+    with pytest.raises(RuntimeError, match="out of range"):
+        ops.check_pairs(ok, n, n - 1)                      # e.g. a full-graph list scored against a halo-compact table
+    ok[1, 0] = n + 5                                        # in-place edit bumps the version
+    with pytest.raises(RuntimeError, match="out of range"):
+        ops.aux_forward(3, 4, 16, 64, ok, n, x, p4, p4, p4[0].contiguous(), 0, 4)
+    from edgedisentangle_ssl_amd import sampling
+    pos = torch.sort(g.row * n + g.col.long()).values
+    smp, _lab = sampling.sample_pairs(n, pos)
+    assert smp._disgat_checked == (n, n, smp._version)
+    with pytest.raises(RuntimeError, match="out of range"):
+        ops.check_pairs(smp, max(1, int(smp[0].max())), n)   # a sampled list reused on a smaller row shard
 
 
 def test_hip_graph_replay_equals_eager(golden_dir, dev):

@@ -59,6 +59,30 @@ def _worker(rank, world, port, q):
         xe = parallel.all_gather_rows(torch.full((4, 3), float(rank)), eq)
         assert torch.equal(xe, torch.arange(world, dtype=torch.float32).repeat_interleave(4).unsqueeze(1).expand(-1, 3))
 
+        # pipelined exchange: the gather is handed over while its slices are still in flight; the column-side projection
+        # consumes them as they land (own rows first), its adjoint reduce-scatters grad x back to the owners
+        for slices in ("1", "3", "64"):
+            os.environ["DISGAT_EXCHANGE_SLICES"] = slices
+            xp = x[lo:lo + dg.n].clone().requires_grad_(True)
+            wq = ic.features(5, 16, 24).requires_grad_(True)
+            xg_, g_eff = parallel.exchange(xp, dg, edge_only=False, pipelined=True)
+            assert g_eff is dg and parallel.pending_of(xg_) is not None
+            qq = parallel.project_gathered(xg_, wq)
+            assert parallel.pending_of(xg_) is None and torch.equal(xg_.detach(), x)
+            assert torch.allclose(qq.detach(), x @ wq.detach(), atol=1e-5)
+            cw = torch.cos(torch.arange(n * 24, dtype=torch.float32).view(n, 24)) * (rank + 1)
+            ((qq * cw).sum() + (xg_ * w).sum()).backward()
+            cw_tot = torch.cos(torch.arange(n * 24, dtype=torch.float32).view(n, 24)) * 3.0
+            want_x = (cw_tot @ wq.detach().t() + torch.arange(n, dtype=torch.float32).unsqueeze(1) * 3.0)[lo:lo + dg.n]
+            assert torch.allclose(xp.grad, want_x, atol=1e-4)
+            assert torch.allclose(wq.grad, x.t() @ (cw_tot / 3.0 * (rank + 1)), atol=1e-3)
+            # finish() without a projection (att 1 / 2: the table is only gathered from)
+            xg2, _ = parallel.exchange(x[lo:lo + dg.n].clone(), dg, edge_only=False, pipelined=True)
+            assert torch.equal(parallel.finish(xg2), x) and parallel.pending_of(xg2) is None
+        os.environ.pop("DISGAT_EXCHANGE_SLICES")
+        xe2, _ = parallel.exchange(torch.full((4, 3), float(rank)), eq, edge_only=False, pipelined=True)     # equal counts
+        assert torch.equal(parallel.finish(xe2), xe)
+
         # one sharded layer (oracle as the math) == unsharded layer on the owned rows
         p = ic.make_params(shapes_layer("SAGE", 3, 16, 16), 9)
         ei_local = torch.stack([dg.row + lo, dg.col.long()])

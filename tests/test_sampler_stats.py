@@ -100,3 +100,43 @@ def test_sampler_on_a_row_shard():
         assert [float(f in full) for f in glob] == lab.tolist()
         seen_pos += int(lab.sum())
     assert seen_pos >= g.nnz // 3 - 3
+
+
+def test_ranks_draw_their_own_streams_and_pool_to_the_unsharded_sample():
+    """main.run reseeds every rank after the replicated set-up (main.reseed_rank): two equal-size shards must not score
+    the same (local row, column) negatives, a rank's stream must be repeatable, and the lists pooled over the ranks
+    must have the unsharded sample's size distribution (K ~ Binomial(N^2, 3 rho) random entries + a third of the
+    positives)."""
+    from edgedisentangle_ssl_amd import main as drop_in
+    from edgedisentangle_ssl_amd import sampling
+    n, world = 64, 2
+    rng = np.random.default_rng(3)
+    flat_all = np.unique(rng.integers(0, n * n, 150))
+    npos = flat_all.size
+    p3 = 3.0 * npos / (n * n)
+    half = n // world
+    shards = []
+    for r in range(world):
+        own = flat_all[(flat_all // n >= r * half) & (flat_all // n < (r + 1) * half)]
+        shards.append(torch.from_numpy(own - r * half * n))            # local rows, global columns
+    totals, same = [], 0
+    for rep in range(200):
+        lists = []
+        for r in range(world):
+            drop_in.reseed_rank(1000 + rep, r)
+            idx, lab = sampling.sample_pairs(half, shards[r], n_cols=n, n_pos_global=npos)
+            assert torch.equal(lab, torch.isin(idx[0] * n + idx[1], shards[r]).float())
+            lists.append(idx)
+        drop_in.reseed_rank(1000 + rep, 1)
+        again, _ = sampling.sample_pairs(half, shards[1], n_cols=n, n_pos_global=npos)
+        assert torch.equal(again, lists[1])                             # a rank's stream repeats under its seed
+        neg = [set((i[0] * n + i[1]).tolist()) - set(s.tolist()) for i, s in zip(lists, shards)]
+        same += len(neg[0] & neg[1]) / max(1, min(len(neg[0]), len(neg[1])))
+        totals.append(sum(i.shape[1] for i in lists))
+    assert same / 200 < 0.3, same / 200             # identical streams share ~all negatives, independent ones ~3 rho = 0.11
+    third = sum(int(s.numel()) // 3 for s in shards)
+    mean = n * n * p3 + third * (1 - p3)
+    var = (n * n - third) * p3 * (1 - p3)
+    t = np.asarray(totals, dtype=np.float64)
+    assert abs(t.mean() - mean) < 4 * np.sqrt(var / t.size), (t.mean(), mean)
+    assert 0.7 * var < t.var() < 1.4 * var, (t.var(), var)
