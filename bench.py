@@ -614,8 +614,9 @@ def main():
                    "nodes_per_rank": graph.n if strong else o.nodes, "nnz_total": int(nnz_total), "feat": o.feat,
                    "heads": o.heads, "att": o.att, "gnn_type": o.gnn_type, "parallelism": f"row-range x{world}",
                    "ranks_seen": world, "backend": None if world == 1 else dist.get_backend(),
-                   "exchanges_per_step": None if world == 1 else ("3 (layer-1 input gathered once: --static-exchange)"
-                                                                  if o.static_exchange else "6 all-gathers of the layer input"),
+                   "exchanges_per_step": None if world == 1 else (
+                       ("3 (layer-1 input gathered once: --static-exchange)" if o.static_exchange else "6 all-gathers of the layer input")
+                       + f", pipelined: {os.environ.get('DISGAT_EXCHANGE_SLICES', '4')} async slices each, own rows + landed slices projected while the rest is on the links"),
                    "gemm_scheme": ops_gemm_mode(), "gemm_check": gemm_chk,
                    "csr_build_ms": None if getattr(graph, "prep_ms", None) is None else round(graph.prep_ms, 1)},
         "roofline": roof, "cpu_baseline": cpu, "secondary": secondary,

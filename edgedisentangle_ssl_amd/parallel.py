@@ -127,7 +127,9 @@ class PendingGather:
             if r == self.rank or n == 0:
                 continue
             g0 = self.offsets[r] + l
-            self.x_all[g0: g0 + n] = tmp[r * ms: r * ms + n]
+            # a raw fill of the buffer, never an autograd op: by now x_all is the OUTPUT of _AllGatherRows, and a tracked
+            # in-place copy would cut these rows out of its backward (their gradient must reach the reduce-scatter)
+            self.x_all.data[g0: g0 + n] = tmp[r * ms: r * ms + n]
             ranges.append((g0, g0 + n))
         if self.next >= len(self.slices):
             _PENDING.pop(self.x_all.data_ptr(), None)

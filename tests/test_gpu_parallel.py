@@ -102,12 +102,13 @@ def _worker(rank, world, port, q, golden_dir):
                 lv_ref, g_ref = grads_of(full, tr.models, g)
                 lv, g_sh = grads_of(part, tr.models, dg)
                 assert abs(lv - lv_ref) <= 2e-6 * max(1.0, abs(lv_ref)), (gnn, att, nm, lv, lv_ref)
-                for a_, b_ in zip(g_sh, g_ref):
+                names = [f"{type(m).__name__}.{k}" for m in tr.models for k, _p in m.named_parameters()]
+                for pname, a_, b_ in zip(names, g_sh, g_ref):
                     if b_ is None:
                         assert a_ is None or float(a_.abs().max()) == 0.0
                         continue
                     err = (a_ - b_).abs().max().item()
-                    assert err <= 2e-4 * max(1e-3, b_.abs().max().item()), (gnn, att, nm, err, b_.abs().max().item())
+                    assert err <= 2e-4 * max(1e-3, b_.abs().max().item()), (gnn, att, nm, pname, err, b_.abs().max().item())
         dist.barrier()
         dist.destroy_process_group()
         q.put((rank, "ok"))

@@ -76,9 +76,13 @@ def _worker(rank, world, port, q):
             want_x = (cw_tot @ wq.detach().t() + torch.arange(n, dtype=torch.float32).unsqueeze(1) * 3.0)[lo:lo + dg.n]
             assert torch.allclose(xp.grad, want_x, atol=1e-4)
             assert torch.allclose(wq.grad, x.t() @ (cw_tot / 3.0 * (rank + 1)), atol=1e-3)
-            # finish() without a projection (att 1 / 2: the table is only gathered from)
-            xg2, _ = parallel.exchange(x[lo:lo + dg.n].clone(), dg, edge_only=False, pipelined=True)
-            assert torch.equal(parallel.finish(xg2), x) and parallel.pending_of(xg2) is None
+            # finish() without a projection (att 1 / 2: the table is only gathered from) - the late fills of the buffer
+            # must not cut the other ranks' rows out of the gather's backward
+            xq = x[lo:lo + dg.n].clone().requires_grad_(True)
+            xg2, _ = parallel.exchange(xq, dg, edge_only=False, pipelined=True)
+            assert torch.equal(parallel.finish(xg2).detach(), x) and parallel.pending_of(xg2) is None
+            (xg2 * w).sum().backward()
+            assert torch.allclose(xq.grad, want)
         os.environ.pop("DISGAT_EXCHANGE_SLICES")
         xe2, _ = parallel.exchange(torch.full((4, 3), float(rank)), eq, edge_only=False, pipelined=True)     # equal counts
         assert torch.equal(parallel.finish(xe2), xe)

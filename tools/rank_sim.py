@@ -29,7 +29,8 @@ def _fake_gather(x, g):
 
 
 parallel.all_gather_rows = _fake_gather
-parallel.exchange = lambda x, g, edge_only: (_fake_gather(x, g), g)
+parallel.exchange = lambda x, g, edge_only, pipelined=False: (_fake_gather(x, g), g)
+parallel.all_reduce_max = lambda t, g: t
 parallel.all_reduce_sum = lambda t, g: t
 a, enc, trainers, graph, x, lists = bench.build_workload(o, 0, world, dev)
 for _ in range(1):
