@@ -7,7 +7,7 @@ travels to the GPU box); the product never imports this.  The reference's .py
 files are imported in place with an in-memory `ipdb` stub; nothing
 is copied out of them - fixtures hold inputs-by-seed and expected OUTPUTS only.
 
-Usage:  python oracle/gen_golden.py [--only tiny|prims|traj|labels|real]
+Usage:  python oracle/gen_golden.py [--only tiny|prims|traj|traj_real|labels|real]
 """
 import argparse
 import os
@@ -304,6 +304,103 @@ def gen_trajectory():
         print("trajectory", gnn, att, "losses", np.round(out["losses"], 5).tolist())
 
 
+def pack_param(out, key, v):
+    """Real-graph trajectory fixtures stay small: the first 256 rows of a parameter + its sum and abs-sum (float64)."""
+    a = np32(v)
+    out[key] = a[:256] if a.ndim else a
+    out[key + "#sum"] = np.float64(a.astype(np.float64).sum())
+    out[key + "#abs"] = np.float64(np.abs(a.astype(np.float64)).sum())
+
+
+def gen_trajectory_real():
+    """The tiny-graph trajectory above at the real configuration (BASELINE configs[0] / [1]): Cora (bundled adjacency +
+    the seeded surrogate features) and chameleon (real features), H = 8, nhid = 64, two epochs of ClsTrainer step ->
+    SupEdge -> DisEdge -> DifHead (main.py:313-352's order) with the reference's trainers (pretrainer.py:709-763, 578-641,
+    810-847; trainer.py:178-223) and injected pair lists, dropout 0."""
+    for name, combos in (("cora", (("AT", 3), ("SAGE", 1))), ("chameleon", (("AT", 3),))):
+        gen_trajectory_on(name, combos)
+
+
+def gen_trajectory_on(name, combos):
+    import random
+    import trainer as ref_trainer
+    idx, labels, feat, n = load_real(name)
+    ei = torch.from_numpy(idx)
+    lab = torch.from_numpy(labels)
+    x = torch.from_numpy(feat) if feat is not None else ic.features(51, n, 64, "cora_surrogate")
+    adj = sparse_adj(ei, torch.ones(ei.shape[1]), n)
+    pos, homo, het = ic.edge_sets(ei, lab, n)
+    sup_idx, sup_lab = ic.sample_pairs(61, n, pos, "sup")
+    ho_idx, ho_lab = ic.sample_pairs(62, n, homo, "homo")
+    he_idx, he_lab = ic.sample_pairs(63, n, het, "het")
+    # conditioning probe: the same run on inputs perturbed by ~2 ulp.  Adam divides by sqrt(v): an element whose gradient is
+    # a cancelling sum at fp32 noise level takes a +-lr step of EITHER sign, in the reference itself - how far each
+    # parameter moves under that perturbation is recorded (`#sens`) and bounds what any fp32 implementation can be held to.
+    pert = torch.from_numpy(np.random.Generator(np.random.PCG64(7)).standard_normal(tuple(x.shape)).astype(np.float32))
+    x_pert = x * (1.0 + 2.4e-7 * pert)
+    for gnn, att in combos:
+        seed = 300 + att
+
+        def run_once(xin, full=None):
+            a = ref_args(gnn, att, 8, 64, 64, extra=("--reg",) if att != 1 else ())
+            a.lr, a.weight_decay = 0.01, 5e-4
+            enc = ic.load_params(ref_models.DISGAT(a, nfeat=64, nhid=64, nclass=64, nheads=8, dropout=0.0), seed)
+            random.seed(5)
+            ct = ref_trainer.ClsTrainer(a, enc, lab, 1.5)
+            ic.load_params(ct.fuse1, seed + 41)
+            ic.load_params(ct.fuse2, seed + 42)
+            ic.load_params(ct.classifier, seed + 43)
+            trs = []
+            for k, cls in enumerate((ref_pre.SupEdgeTrainer, ref_pre.GeneratedEdgeTrainer, ref_pre.DifHeadTrainer)):
+                tr = cls(a, enc, [1.0, 0.5, 2.0][k])
+                ic.load_params(tr.fuse1, seed + 1 + 10 * k)
+                ic.load_params(tr.fuse2, seed + 2 + 10 * k)
+                trs.append(tr)
+            ic.load_params(trs[2].classifier1, seed + 4)
+            ic.load_params(trs[2].classifier2, seed + 5)
+            inject_sampler(trs[0], (sup_lab, [sup_idx]))
+            trs[1].dis_adjs = [None, None]
+            inject_sampler(trs[1], ([ho_lab, he_lab], [ho_idx, he_idx]))
+            logs, cls_logs = [], []
+            for ep in range(2):
+                lg = ct.train_step((xin, adj), lab, ep)
+                cls_logs.append([lg[k] for k in ("loss_train", "acc_train", "loss_reg", "loss_val", "acc_val")])
+                logs.append(trs[0].train_step((xin, adj), None)["loss_heads_sup"])
+                logs.append(trs[1].train_step((xin, adj))["loss_head_disen"])
+                logs.append(trs[2].train_step((xin, adj))["loss_head_diversity"])
+            params = {}
+            for nm in ("fuse1", "fuse2", "classifier"):
+                for k, v in getattr(ct, nm).state_dict().items():
+                    params[f"cls.{nm}.{k}"] = v.detach().clone()
+            for k, v in enc.state_dict().items():
+                params["enc." + k] = v.detach().clone()
+            for t, tr in enumerate(trs):
+                for nm in ("fuse1", "fuse2"):
+                    for k, v in getattr(tr, nm).state_dict().items():
+                        params[f"t{t}.{nm}.{k}"] = v.detach().clone()
+            for nm in ("classifier1", "classifier2"):
+                for k, v in getattr(trs[2], nm).state_dict().items():
+                    params[f"t2.{nm}.{k}"] = v.detach().clone()
+            idxs = {nm: getattr(ct, nm).numpy().astype(np.int16) for nm in ("idx_train", "idx_val", "idx_test")}
+            return params, np.asarray(logs, dtype=np.float64), np.asarray(cls_logs, dtype=np.float64), idxs
+
+        params, logs, cls_logs, idxs = run_once(x)
+        params_p, logs_p, cls_logs_p, _ = run_once(x_pert)
+        out = {"cls_logs": cls_logs, "losses": logs.astype(np.float32), **idxs,
+               "losses#sens": np.abs(logs - logs_p), "cls_logs#sens": np.abs(cls_logs - cls_logs_p)}
+        worst = (0.0, "")
+        for k, v in params.items():
+            pack_param(out, k, v)
+            dp = (v.double() - params_p[k].double()).abs()
+            sens = float(dp.max())
+            out[k + "#sens"] = np.float64(sens)
+            out[k + "#nflip"] = np.int64(int((dp > 4e-4).sum()))      # elements the 2-ulp perturbation moves by more than PTOL
+            worst = max(worst, (sens, k))
+        np.savez_compressed(os.path.join(GOLD, f"{name}_traj_{gnn}_att{att}.npz"), **out)
+        print(name, "trajectory", gnn, att, "losses", np.round(out["losses"], 5).tolist(), "cls", np.round(out["cls_logs"][-1], 5).tolist(),
+              "| most perturbation-sensitive parameter", worst, "loss sens", out["losses#sens"].max())
+
+
 def gen_labels():
     """GeneratedEdgeTrainer.get_label_all (pretrainer.py:386-513) on the tiny graph: the homo / hetero edge groups with every
     node label known (:448-456) and under --conformT (:465-498, train + val nodes of utils.split only), as flat row*N+col ids."""
@@ -430,6 +527,8 @@ if __name__ == "__main__":
             gen_tiny()
         if o.only in (None, "traj"):
             gen_trajectory()
+        if o.only in (None, "traj", "traj_real"):
+            gen_trajectory_real()
         if o.only in (None, "labels"):
             gen_labels()
         if o.only in (None, "real"):
