@@ -557,7 +557,8 @@ def main():
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
         w = tj["workload"]
         if (w["nodes"], w["edges"], w["feat"], w["heads"], w["att"], w["gnn_type"], w["n_gpus"]) == \
-                (o.nodes, o.edges, o.feat, o.heads, o.att, o.gnn_type, world) and not o.fwd_only:
+                (o.nodes, o.edges, o.feat, o.heads, o.att, o.gnn_type, world) and not o.fwd_only \
+                and set(tj["bytes_per_launch"]) <= set(agg):       # every profiled kernel is one this run launched
             traffic = tj["bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         pass

@@ -12,6 +12,7 @@ over; the sparse forward of all heads of a layer is ONE fused HIP edge pass
   disga_heads()     the H-head loop of models.py:225-228 / 240-243 as one call
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -158,6 +159,12 @@ def _memo(layers, tag, build):
         return build()          # only eval-mode, graph-free forwards reuse (writes through `param.data` do not bump
                                 # the version counter: call layers.clear_weight_cache(module) after such an edit)
     key = tuple((id(p), p.data_ptr(), p._version) for p in params)
+    if os.environ.get("DISGAT_STRICT_CACHE") == "1":
+        # writes through `param.data` do not bump the version counter: with the strict switch the key also carries a
+        # checksum of the parameter VALUES (one small reduction + one host read per use - for drop-in users who edit
+        # weights in place and cannot call clear_weight_cache)
+        with torch.no_grad():
+            key += (tuple(torch.stack([p.detach().double().sum() + p.detach().double().abs().sum() * 3.0 for p in params]).tolist()),)
     cache = layers[0].__dict__.setdefault("_disgat_memo", {})
     hit = cache.get(tag)
     if hit is not None and hit[0] == key:

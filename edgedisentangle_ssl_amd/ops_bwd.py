@@ -241,9 +241,11 @@ def layer_backward(ctx, gz, ge, gaux):
         ectx = SimpleNamespace(saved_tensors=(x, rowop, colop, a, z, edge_e, den), cfg=(graph, att, H, f_in, f_out, sage, drop),
                                needs_input_grad=ctx.needs_input_grad, sign=ctx.sign)
         g_x, g_row, g_col, g_a, _, _ge = edge_backward(ectx, gz, ge)
+    ctx.sign = None                    # 256 B per edge: the record is dead once both segment passes have read it
     chunk = ops.CHUNK[att]
     n_rows, n_cols = rowop.shape[0], colop.shape[0]
-    for pairs, (lo, hi), sign, gout in zip(lists, ranges, ctx.aux_signs, gaux):
+    for li, (pairs, (lo, hi), gout) in enumerate(zip(lists, ranges, gaux)):
+        sign, ctx.aux_signs[li] = ctx.aux_signs[li], None          # 256 B per pair (17 GB for a 66M-pair list): freed list by list
         if gout is None or sign is None:
             continue
         gout = gout.contiguous()
@@ -257,4 +259,5 @@ def layer_backward(ctx, gz, ge, gaux):
             g_col, ga = _seg_sign(wi, perm32, gout, lo, hi, H, f_out, sign, colop, a, n_cols, need_a, into=g_col)
             if need_a:
                 g_a = ga if g_a is None else g_a + ga
+        del sign
     return (g_x, g_row if need_row else None, g_col if need_col else None, g_a if need_a else None, None) + (None,) * len(lists)

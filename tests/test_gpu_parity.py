@@ -307,3 +307,29 @@ def test_degenerate_inputs(dev, gnn, att):
                 close(e_list[h][:, 0], e[:, 0], what=f"{name}: edge_e {h}")
             assert aux_out[h][0].shape == (0, 1)
             close(aux_out[h][1][:, 0], au[1][:, 0], what=f"{name}: aux {h}")
+
+
+def test_weight_cache_and_data_edits(dev, monkeypatch):
+    """Eval-mode forwards reuse the packed / split weights of a layer (layers._memo) keyed on the parameters' versions.
+    An in-place op bumps the version and rebuilds; a write through `.data` does not - it is served stale unless
+    layers.clear_weight_cache() is called or DISGAT_STRICT_CACHE=1 adds a value checksum to the key."""
+    from edgedisentangle_ssl_amd import layers
+    x, adj, n, _ = tiny_inputs(dev)
+    a, enc, fus = build("AT", 3, 4, 16, 16, 77, dev)
+    with torch.no_grad():
+        base = enc.get_em(x, adj, fus)[1].clone()
+        enc.attention1_0.W_em.mul_(1.5)                         # tracked in-place edit: new version, rebuilt
+        moved = enc.get_em(x, adj, fus)[1].clone()
+        assert float((moved - base).abs().max()) > 1e-4
+        enc.attention1_0.W_em.data.mul_(1.0 / 1.5)              # untracked edit back to the start
+        stale = enc.get_em(x, adj, fus)[1].clone()
+        layers.clear_weight_cache(enc)
+        fresh = enc.get_em(x, adj, fus)[1].clone()
+    assert torch.equal(stale, moved), "documented trap: .data edits are invisible to the version key"
+    assert float((fresh - base).abs().max()) <= 1e-6 * max(1.0, float(base.abs().max()))
+    monkeypatch.setenv("DISGAT_STRICT_CACHE", "1")
+    with torch.no_grad():
+        enc.get_em(x, adj, fus)
+        enc.attention1_0.W_em.data.mul_(1.5)
+        strict = enc.get_em(x, adj, fus)[1]
+    assert float((strict - moved).abs().max()) <= 1e-6 * max(1.0, float(moved.abs().max()))

@@ -1,16 +1,37 @@
 #!/usr/bin/env python3
-"""Runs the split GEMM a few times on one DISGAT shape (for rocprofv3 PMC passes)."""
+"""Runs ONE dense contraction of the DISGAT path a few times (for rocprofv3 PMC passes), M = 1,000,000 rows:
+  tools/gemm_one.py pq       x [M,256] @ [256,2048]          fp32 operand, A-stationary kernel (P / Q score operands)
+  tools/gemm_one.py proj     Z planes [M,8,256] @ [8,256,256] -> ELU -> head planes      (disgat_gemm_planes)
+  tools/gemm_one.py fuser    head planes [M,2048] @ [2048,256] + bias, leaky ReLU -> fp32 (disgat_gemm_planes)
+  tools/gemm_one.py K N      fp32 operand [M,K] @ [K,N] on the fp32-input kernels (round-2 form)"""
 import os
 import sys
 
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from edgedisentangle_ssl_amd import ops_gemm  # noqa: E402
+from edgedisentangle_ssl_amd import ops_gemm as og  # noqa: E402
 
-M, K, N = 1_000_000, int(sys.argv[1]), int(sys.argv[2])
-a = torch.randn(M, K, device="cuda")
-w = torch.randn(K, N, device="cuda") * 0.05
+M = 1_000_000
+what = sys.argv[1]
+if what == "proj":
+    a = torch.randn(M, 8, 256, device="cuda").permute(1, 0, 2)
+    w = torch.randn(8, 256, 256, device="cuda") * 0.05
+    ap, wr = og.split_planes(a), og.presplit_rm(w)
+    bound = (ap.bound * w.abs().sum(1).max()).reshape(1)
+    fn = lambda: og.linear_planes(ap, wr, 256, None, None, og.ACT_ELU, 0.0, False, bound)      # noqa: E731
+elif what == "fuser":
+    h = torch.randn(M, 2048, device="cuda")
+    w = torch.randn(2048, 256, device="cuda") * 0.02
+    b = torch.randn(256, device="cuda")
+    hp, wr = og.split_planes(h), og.presplit_rm(w)
+    fn = lambda: og.linear_planes(hp, wr, 256, b, None, og.ACT_LEAKY, 0.01)                     # noqa: E731
+else:
+    K, N = (256, 2048) if what == "pq" else (int(sys.argv[1]), int(sys.argv[2]))
+    a = torch.randn(M, K, device="cuda")
+    w = torch.randn(K, N, device="cuda") * 0.05
+    am, ws = og.amax(a), og.presplit(w)
+    fn = lambda: og._forward(a, w, None, None, 0, 0.0, am, ws)                                  # noqa: E731
 for _ in range(4):
-    ops_gemm._forward(a, w, None, None, 0, 0.0)
+    fn()
 torch.cuda.synchronize()

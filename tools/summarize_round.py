@@ -79,29 +79,33 @@ def main(src, dst):
     # GEMM PMC
     with open(os.path.join(dst, "gemm_f16x3_pmc.md"), "w") as out:
         P = lambda *a: print(*a, file=out)      # noqa: E731
-        P("# f16x3 GEMM kernels: PMC counters (tools/gemm_one.py K N, M = 1,000,000, 4 launches, per-launch averages)\n")
+        P("# f16x3 GEMM kernels: PMC counters (tools/gemm_one.py pq | proj | fuser, M = 1,000,000, 4 launches, per-launch averages)\n")
         P("Separate rocprofv3 passes per counter set (SQ set 1, SQ set 2, FETCH_SIZE, WRITE_SIZE) plus a kernel-trace pass "
           "for the duration.  SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles; SQ_VALU_MFMA_BUSY_CYCLES "
           "counts cycles (MI355X_MICROARCH.md).\n")
-        for shape, what in (("256x2048", "P / Q operands [1e6,256] x [256,2048]: gemm_f16x3_as_kernel<0> (A-stationary)"),
-                            ("2048x256", "FuseLayer [1e6,2048] x [2048,256]: gemm_f16x3_kernel (tiled)")):
+        for shape, what, flop, kname in (
+                ("pq", "P / Q operands x[1e6,256] x [256,2048], fp32 operand: gemm_f16x3_as_kernel<0> (A-stationary)", 2.0e6 * 256 * 2048, "gemm_f16x3"),
+                ("proj", "per-head projection, Z planes [1e6,8,256] x [8,256,256] -> ELU -> head planes: gemm_planes_kernel<1,false,true>", 2.0e6 * 8 * 256 * 256, "gemm_planes"),
+                ("fuser", "FuseLayer, head planes [1e6,2048] x [2048,256] + bias, leaky ReLU -> fp32: gemm_planes_kernel<2,true,false>", 2.0e6 * 2048 * 256, "gemm_planes")):
             P(f"\n## {what}\n")
-            kt = [r for r in one(os.path.join(src, f"gemm_{shape}_kt")) if "gemm" in r["Name"]]
+            kt = [r for r in one(os.path.join(src, f"gemm_{shape}_kt")) if kname in r["Name"]]
             dur = None
             for r in kt:
                 dur = float(r["AverageNs"]) / 1e6
                 P(f"`{r['Name'][:80]}`: {r['Calls']} calls, avg **{dur:.3f} ms** "
-                  f"({2.0 * 1e6 * 256 * 2048 / (dur * 1e-3) / 1e12:.0f} TFLOP/s fp32-equivalent, x3 fp16 MFMA products inside)\n")
+                  f"({flop / (dur * 1e-3) / 1e12:.0f} TFLOP/s fp32-equivalent, x3 fp16 MFMA products inside)\n")
             P("| counter | per launch |\n|---|---|")
             vals = {}
             for sub in ("sq1", "sq2", "fetch", "write"):
                 for k, cs in counters(os.path.join(src, f"gemm_{shape}_{sub}")).items():
-                    if "gemm_f16x3" not in k:
+                    if kname not in k:
                         continue
                     for c, v in cs.items():
                         vals[c] = sum(v) / len(v)
             for c, v in vals.items():
                 P(f"| {c} | {v:.4g} |")
+            if "SQ_INSTS_VALU" in vals and "SQ_INSTS_MFMA" in vals:
+                P(f"\nVALU : MFMA instructions = {vals['SQ_INSTS_VALU'] / vals['SQ_INSTS_MFMA']:.2f}")
             if "SQ_VALU_MFMA_BUSY_CYCLES" in vals and dur:
                 # 1024 SIMDs (256 CUs x 4); the counter sums busy cycles over all SIMDs
                 for ghz in (2.4, 2.0):
@@ -114,6 +118,34 @@ def main(src, dst):
                 w = vals["SQ_WAVE_CYCLES"]
                 P(f"\nWave time: {vals['SQ_ACTIVE_INST_ANY'] / w * 100:.0f} % issuing, {vals['SQ_WAIT_INST_ANY'] / w * 100:.0f} % "
                   f"issue-stalled, {vals['SQ_WAIT_ANY'] / w * 100:.0f} % parked at s_waitcnt / barrier")
+    with open(os.path.join(dst, "att2_pmc.md"), "w") as out:
+        P = lambda *a: print(*a, file=out)      # noqa: E731
+        P("# att 2 (the reference's default --att): edge pass and aux scorer, PMC counters (tools/kbench.py --att 2 --what edge aux)\n")
+        P("C4 graph (1M nodes / 20M edges, F = 256, H = 8); per-launch averages; separate rocprofv3 passes per counter set.\n")
+        kt = {r["Name"].split("(")[0]: r for r in one(os.path.join(src, "att2_kt")) if "disgat" in r["Name"]}
+        vals = {}
+        for sub in ("sq1", "sq2", "fetch", "write"):
+            for k, cs in counters(os.path.join(src, f"att2_{sub}")).items():
+                if "disgat" in k:
+                    for c, v in cs.items():
+                        vals.setdefault(k, {})[c] = sum(v) / len(v)
+        for k, cs in vals.items():
+            name = next((n for n in kt if n.startswith(k[:60])), None)
+            dur = float(kt[name]["AverageNs"]) / 1e6 if name else None
+            P(f"\n## `{k[:110]}`" + (f" - avg {dur:.3f} ms" if dur else "") + "\n")
+            P("| counter | per launch |\n|---|---|")
+            for c, v in cs.items():
+                P(f"| {c} | {v:.4g} |")
+            if all(c in cs for c in ("SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY")):
+                w = cs["SQ_WAVE_CYCLES"]
+                P(f"\nWave time: {cs['SQ_ACTIVE_INST_ANY'] / w * 100:.0f} % issuing, {cs['SQ_WAIT_INST_ANY'] / w * 100:.0f} % issue-stalled, "
+                  f"{cs['SQ_WAIT_ANY'] / w * 100:.0f} % parked at s_waitcnt")
+            if "SQ_ACTIVE_INST_VALU" in cs and "SQ_BUSY_CYCLES" in cs:
+                P(f"\nVALU-active quad-cycles / SQ busy cycles = {cs['SQ_ACTIVE_INST_VALU'] / cs['SQ_BUSY_CYCLES']:.2f}")
+            if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs and dur:
+                by = (2 * cs["FETCH_SIZE"] + cs["WRITE_SIZE"]) * 1024
+                P(f"\nHBM bytes per launch (2 x FETCH + WRITE): {by / 1e9:.2f} GB -> {by / (dur * 1e-3) / 1e12:.2f} TB/s moved")
+    print(open(os.path.join(dst, "att2_pmc.md")).read())
     print(open(os.path.join(dst, "gemm_f16x3_pmc.md")).read())
     print(open(os.path.join(dst, "kt_c4_att3_summary.md")).read())
 

@@ -38,13 +38,28 @@ def fwd_only():
         return sup.loss(data, sl, [si]) + dis.loss(data, [hl, tl], [hi, ti]) + dif.loss(data)
 
 
+PEAKS = {}
+
+
 def train():
     out = []
-    for tr, fn in ((sup, lambda: sup.loss(data, sl, [si])), (dis, lambda: dis.loss(data, [hl, tl], [hi, ti])),
-                   (dif, lambda: dif.loss(data))):
+    for nm, tr, fn in (("sup", sup, lambda: sup.loss(data, sl, [si])), ("dis", dis, lambda: dis.loss(data, [hl, tl], [hi, ti])),
+                       ("dif", dif, lambda: dif.loss(data))):
         tr._begin_step()
-        loss = fn()
-        tr._finish_step(loss, graph)
+        if os.environ.get("TRAIN_BENCH_PEAKS") == "1":
+            torch.cuda.synchronize()
+            torch.cuda.reset_peak_memory_stats()
+            loss = fn()
+            torch.cuda.synchronize()
+            PEAKS[nm + " end of forward (held)"] = torch.cuda.memory_allocated() / 2 ** 30
+            PEAKS[nm + " forward peak"] = torch.cuda.max_memory_allocated() / 2 ** 30
+            torch.cuda.reset_peak_memory_stats()
+            tr._finish_step(loss, graph)
+            torch.cuda.synchronize()
+            PEAKS[nm + " backward peak"] = torch.cuda.max_memory_allocated() / 2 ** 30
+        else:
+            loss = fn()
+            tr._finish_step(loss, graph)
         out.append(loss.detach())
     return out
 
@@ -59,3 +74,6 @@ for name, fn in (("forward only (eval)", fwd_only), ("train (fwd+bwd+Adam, dropo
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t) / n
     print(f"{name:44s} {dt * 1e3:9.2f} ms/iter  {graph.nnz / dt:.3e} edges/s   peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+if os.environ.get("TRAIN_BENCH_PEAKS") == "1":
+    for k, v in PEAKS.items():
+        print(f"  {k:32s} {v:7.1f} GiB")
