@@ -272,6 +272,10 @@ class HaloPlan:
         _a2a(want, ref, self.send_counts, self.recv_counts, group)
         self.send_idx = (want - graph.row_start).contiguous()
         assert self.send_idx.numel() == 0 or (int(self.send_idx.min()) >= 0 and int(self.send_idx.max()) < graph.n)
+        # adjoint: the rows every peer sends back are summed per owner row in a FIXED order (sorted once here, segmented
+        # sum in the backward) - index_add_'s float atomics made the halo path's gradients vary run to run
+        self.back_order = torch.sort(self.send_idx, stable=True).indices
+        self.back_lengths = torch.bincount(self.send_idx, minlength=graph.n)
         self.ref = ref
         self.n_ref = int(ref.numel())
         self.group = group
@@ -296,8 +300,9 @@ class _HaloRows(torch.autograd.Function):
         plan = ctx.plan
         back = g.new_empty((plan.send_idx.numel(),) + tuple(g.shape[1:]))
         _a2a(back, g.contiguous(), plan.send_counts, plan.recv_counts, plan.group)
-        gx = g.new_zeros((plan.graph_c.n,) + tuple(g.shape[1:]))
-        gx.index_add_(0, plan.send_idx, back)
+        if back.shape[0] == 0:
+            return g.new_zeros((plan.graph_c.n,) + tuple(g.shape[1:])), None
+        gx = torch.segment_reduce(back[plan.back_order], "sum", lengths=plan.back_lengths, axis=0, initial=0.0)
         return gx, None
 
 
@@ -359,6 +364,9 @@ def exchange(x_local, graph, edge_only, pipelined=False):
     return _AllGatherRows.apply(x_local, graph.counts, graph.group, exchange_slices(), bool(pipelined)), graph
 
 
+_SEEN_FLAGS = {}
+
+
 def all_reduce_grads(modules, graph):
     """Data-parallel gradient reduction: every rank holds the replicated parameters and the gradient
     contribution of its own rows / pairs; the global gradient is their sum.  The bucket covers EVERY parameter
@@ -370,10 +378,21 @@ def all_reduce_grads(modules, graph):
     params = [p for m in modules for p in m.parameters() if p.requires_grad]
     if not params:
         return
-    has = torch.tensor([0.0 if p.grad is None else 1.0 for p in params], dtype=params[0].dtype, device=params[0].device)
+    local = tuple(p.grad is not None for p in params)
+    has = torch.tensor([1.0 if h else 0.0 for h in local], dtype=params[0].dtype, device=params[0].device)
     flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params] + [has])
     dist.all_reduce(flat, group=graph.group)       # one bucket: a few MB of parameters + one has-grad flag each
-    seen = flat[-len(params):].tolist()
+    # Which parameters got a gradient on SOME rank decides, for the ones with none here, between "stays None" (the
+    # optimiser skips it, as in the unsharded run) and "receives the others' sum".  Only those need the flags on the
+    # host; which parameters no rank ever touches is structural (the encoder's own unused fusers), so the flags are read
+    # back once per (parameter set, local pattern) instead of every step - the step stays free of device syncs.
+    if all(local):
+        seen = [1.0] * len(params)
+    else:
+        key = (tuple(id(p) for p in params), local)
+        seen = _SEEN_FLAGS.get(key)
+        if seen is None:
+            seen = _SEEN_FLAGS[key] = flat[-len(params):].tolist()
     off = 0
     for p, any_rank in zip(params, seen):
         g = flat[off: off + p.numel()].view_as(p)
