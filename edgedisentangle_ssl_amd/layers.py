@@ -231,7 +231,48 @@ def _pack_score_operands(layers, x, x_all, att, H, Hp, f_in, f_out, fp, am=None,
 
     wt, wb, a_vec, st, sb = _memo(layers, ("att3", fp, Hp, c0, c1), pack3)
     p_row = ops_gemm.linear(x, wt, a_amax=am, w_split=st)         # own rows: runs while the all-gather's slices are on the links
-    return p_row, _col_operand(x_all, wb, am, sb), a_vec
+    q_col = _col_operand(x_all, wb, am, sb)
+    # how to rebuild either operand in the backward instead of keeping 2 x [N, H*F_out] floats alive until then (_remat_hooks)
+    p_row._disgat_remat = (x, wt, am, st)
+    q_col._disgat_remat = (x_all, wb, am, sb)
+    return p_row, q_col, a_vec
+
+
+# The att-3 score operands P = x W_top, Q = x_all W_bot ([N, H*F_out] each: 8 GB apiece at C4) are outputs of one GEMM
+# and inputs of one fused pass; the pass's backward needs them again (grad a = sum P (.) u + sum Q (.) v).  Saved, they are
+# the largest thing a training step holds between forward and backward: 2 layers x 2 x 8 GB of a 119 GiB peak.  With
+# REMAT_SCORE_OPERANDS the pass saves the RECIPE instead (input, packed weight - both alive anyway) and the backward
+# recomputes the operand: 4 GEMMs of ~3.3 ms per training step for -32 GB.  DISGAT_REMAT=0 keeps them.
+REMAT_SCORE_OPERANDS = os.environ.get("DISGAT_REMAT", "1") != "0"
+
+
+def _remat_hooks(*operands):
+    table = {t.data_ptr(): (tuple(t.shape), t._disgat_remat) for t in operands
+             if t is not None and getattr(t, "_disgat_remat", None) is not None}
+
+    def pack(t):
+        ent = table.get(t.data_ptr()) if (t.is_cuda and t.dim() == 2) else None
+        if ent is not None and tuple(t.shape) == ent[0] and t.is_contiguous():
+            return ("disgat-remat", ent[1])
+        return t
+
+    def unpack(o):
+        if isinstance(o, tuple) and len(o) == 2 and o[0] == "disgat-remat":
+            a, w, am, ws = o[1]
+            with torch.no_grad():
+                return ops_gemm._forward(a.detach(), w.detach(), None, None, ops_gemm.ACT_NONE, 0.0, am, ws)
+        return o
+
+    return torch.autograd.graph.saved_tensors_hooks(pack, unpack)
+
+
+def _saved_operand_policy(rowop, colop):
+    """Context for a fused pass that saves its score operands: rematerialise them in the backward when they carry a
+    recipe (att 3, one head group) and the switch is on; otherwise a no-op context."""
+    import contextlib
+    if REMAT_SCORE_OPERANDS and torch.is_grad_enabled() and any(getattr(t, "_disgat_remat", None) is not None for t in (rowop, colop)):
+        return _remat_hooks(rowop, colop)
+    return contextlib.nullcontext()
 
 
 def _col_operand(x_all, w, am, w_split):
@@ -365,6 +406,9 @@ def disga_heads(layers, x, adj, aux_indices=None, head_ranges=None, aux_only=Fal
                 ranges = tuple((0, H) if head_ranges is None or head_ranges[li] is None else tuple(head_ranges[li])
                                for li in range(len(aux_indices)))
                 cfg = (graph, att, Hk, f_in_p, fp, gnn == "SAGE", d, ranges)
+                recipes = (getattr(rowop, "_disgat_remat", None), getattr(colop, "_disgat_remat", None))
+                if REMAT_SCORE_OPERANDS and att == 3 and None not in recipes:
+                    cfg = cfg + (recipes,)          # the pass keeps the recipes, not P / Q (ops_bwd.layer_backward_remat)
                 z, edge_e, _den, *merged_aux = ops.LayerPass.apply(xg, r, c, av, cfg, *aux_indices)
             elif use_pl:
                 # no-graph forward: the aggregate leaves the edge pass as the two fp16 planes the projection GEMM consumes
@@ -373,7 +417,8 @@ def disga_heads(layers, x, adj, aux_indices=None, head_ranges=None, aux_only=Fal
             elif f_in_p <= tile:
                 cfg = (graph, att, Hk, f_in_p, fp, gnn == "SAGE", d, rec)
                 e_in = earlier_slices(gi, graph.edge_pairs(), 0, Hk) if len(f_slices) > 1 else None
-                z, edge_e, _den = ops.EdgePass.apply(xg, r, c, av, cfg, e_in)
+                with _saved_operand_policy(rowop, colop):
+                    z, edge_e, _den = ops.EdgePass.apply(xg, r, c, av, cfg, e_in)
             else:
                 zs, edge_e = [], None
                 e_in = earlier_slices(gi, graph.edge_pairs(), 0, Hk) if len(f_slices) > 1 else None
@@ -388,6 +433,12 @@ def disga_heads(layers, x, adj, aux_indices=None, head_ranges=None, aux_only=Fal
             e_groups.append(edge_e)
         z = z_groups[0] if n_groups == 1 else torch.cat(z_groups, dim=1)             # [N, Hp, F_in_p]
         edge_e = e_groups[0] if n_groups == 1 else torch.cat(e_groups, dim=0)        # [Hp, E]
+        if merged_aux is not None or aux_indices is None:
+            # nothing below scores anything any more: drop this frame's references to the score operands (2 x 8 GB at C4)
+            # before the projection / fuser GEMMs allocate their outputs - with the rematerialising passes the operands
+            # are then freed here, in inference at the latest
+            slice_ops.clear()
+            rowop = colop = r = c = None
 
         # ---- per-head output projection on the aggregated neighbourhood (dense, MFMA), written
         # straight into the fused [N, H*F_out] layout the fuser consumes (no torch.cat of heads)

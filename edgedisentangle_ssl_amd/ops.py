@@ -249,7 +249,8 @@ class LayerPass(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, rowop, colop, a, cfg, *lists):
-        graph, att, H, F_in, F_out, sage, drop, ranges = cfg
+        graph, att, H, F_in, F_out, sage, drop, ranges = cfg[:8]
+        ctx.remat = cfg[8] if len(cfg) > 8 else None      # (recipe of P, recipe of Q): rebuild them in the backward
         ctx.sign = sign_record(att, H, F_out, graph.nnz, x.device) if graph.nnz else None
         z, edge_e, den = edge_forward(graph, att, H, F_in, F_out, x, rowop, colop, a, sage, drop, sign=ctx.sign)
         outs, ctx.aux_signs = [], []
@@ -258,8 +259,11 @@ class LayerPass(torch.autograd.Function):
             sg = sign_record(att, H, F_out, m, pairs.device) if m else None
             outs.append(aux_forward(att, H, F_in, F_out, pairs, graph.n, None, rowop, colop, a, lo, hi, sign=sg))
             ctx.aux_signs.append(sg)
-        ctx.cfg = cfg
-        ctx.save_for_backward(x, rowop, colop, a, z, edge_e, den, *lists)
+        ctx.cfg = cfg[:8]
+        if ctx.remat is not None:
+            ctx.save_for_backward(x, a, z, edge_e, den, *lists)
+        else:
+            ctx.save_for_backward(x, rowop, colop, a, z, edge_e, den, *lists)
         ctx.mark_non_differentiable(den)
         ctx.set_materialize_grads(False)      # outputs nobody differentiates arrive as None, and their passes are skipped
         return (z, edge_e, den, *outs)
@@ -267,4 +271,6 @@ class LayerPass(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gz, ge, _gden, *gaux):
         from . import ops_bwd
+        if ctx.remat is not None:
+            return ops_bwd.layer_backward_remat(ctx, gz, ge, gaux)
         return ops_bwd.layer_backward(ctx, gz, ge, gaux)

@@ -229,6 +229,82 @@ def aux_backward(ctx, gout):
     return g_x, g_row, g_col, g_a, None, None
 
 
+def _recompute(recipe):
+    """Score operand from its recipe (input, packed weight, amax, weight planes): the forward's own GEMM again."""
+    from . import ops_gemm
+    a, w, am, ws = recipe
+    with torch.no_grad():
+        return ops_gemm._forward(a.detach(), w.detach(), None, None, ops_gemm.ACT_NONE, 0.0, am, ws)
+
+
+def layer_backward_remat(ctx, gz, ge, gaux):
+    """layer_backward for a pass that saved the RECIPES of P and Q instead of the operands (ops.LayerPass with
+    cfg[8]): att 3 with sign records only.  The row side of the edge list and of every aux list runs first on a
+    recomputed P, which is dropped before Q is rebuilt for the column sides - one 8 GB operand alive at a time instead of
+    two saved ones; the sign records go list by list during the column phase."""
+    x, a, z, edge_e, den, *lists = ctx.saved_tensors
+    graph, att, H, f_in, f_out, sage, drop, ranges = ctx.cfg
+    rec_p, rec_q = ctx.remat
+    need_x, need_row, need_col, need_a = ctx.needs_input_grad[:4]
+    dev = x.device
+    n, e = graph.n, graph.nnz
+    chunk = ops.CHUNK[att]
+    n_rows, n_cols = int(rec_p[0].shape[0]), int(rec_q[0].shape[0])
+    have_edge = (gz is not None or ge is not None) and e > 0
+    ge_tot = beta = t = twi = None
+    if have_edge:
+        wi = graph.work_items(chunk)
+        gz = torch.zeros_like(z) if gz is None else gz.contiguous()
+        ge = None if ge is None else ge.contiguous()
+        ge_tot = torch.empty((H, e), dtype=torch.float32, device=dev)
+        beta = torch.empty((H, e), dtype=torch.float32, device=dev)
+        _lib.call("disgat_bwd_alpha", wi.items.data_ptr(), wi.n_items, graph.col.data_ptr(), e, H, f_in, x.data_ptr(),
+                  x.stride(0), gz.data_ptr(), z.data_ptr(), edge_e.data_ptr(), den.data_ptr(), ops._ptr(ge), ge_tot.data_ptr(),
+                  beta.data_ptr(), int(bool(sage)), float(drop[0]), int(drop[1]), ops._stream())
+        t = graph.transpose()
+        twi = t.work_items(chunk)
+    g_x = g_row = g_col = g_a = None
+
+    def add_ga(ga):
+        nonlocal g_a
+        if need_a and ga is not None:
+            g_a = ga if g_a is None else g_a + ga
+
+    live = [(pairs, rng, sg, go.contiguous()) for pairs, rng, sg, go in zip(lists, ranges, ctx.aux_signs, gaux)
+            if go is not None and sg is not None]
+    # ---- row side: P
+    if need_row or need_a:
+        rowop = _recompute(rec_p)
+        if have_edge:
+            g_row, ga = _seg_sign(wi, None, ge_tot, 0, H, H, f_out, ctx.sign, rowop, a, n, need_a)
+            add_ga(ga)
+        for pairs, (lo, hi), sg, gout in live:
+            wl, _perm, perm32 = _segments_of(pairs, 0, n_rows, chunk)
+            g_row, ga = _seg_sign(wl, perm32, gout, lo, hi, H, f_out, sg, rowop, a, n_rows, need_a, into=g_row)
+            add_ga(ga)
+        del rowop
+    # ---- column side: Q; every record is dead after its column pass
+    if need_col or need_a:
+        colop = _recompute(rec_q)
+        if have_edge:
+            g_col, ga = _seg_sign(twi, t.eid, ge_tot, 0, H, H, f_out, ctx.sign, colop, a, n_cols, need_a)
+            add_ga(ga)
+        ctx.sign = None
+        for li, (pairs, (lo, hi), sg, gout) in enumerate(live):
+            wl, _perm, perm32 = _segments_of(pairs, 1, n_cols, chunk)
+            g_col, ga = _seg_sign(wl, perm32, gout, lo, hi, H, f_out, sg, colop, a, n_cols, need_a, into=g_col)
+            add_ga(ga)
+            live[li] = None
+            sg = None
+        del colop
+    ctx.sign = None
+    ctx.aux_signs = [None] * len(ctx.aux_signs)
+    if have_edge and need_x:
+        g_x = _keybuf(tuple(x.shape), dev, twi, x.stride(0) != f_in)
+        _seg_hx(1, twi, t.col, t.eid, beta, 0, H, H, f_in, gz.view(n, H * f_in), g_x, False)
+    return (g_x, g_row if need_row else None, g_col if need_col else None, g_a if need_a else None, None) + (None,) * len(lists)
+
+
 def layer_backward(ctx, gz, ge, gaux):
     """Backward of ops.LayerPass: the edge list first (stores the operand gradients), then every aux list ADDS its
     share into the same buffers inside seg_grad_sign_kernel."""
