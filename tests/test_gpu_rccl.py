@@ -37,6 +37,24 @@ assert torch.equal(xa.detach(), x)
 w = torch.arange(n, dtype=torch.float32, device=dev).unsqueeze(1)
 (xa * w).sum().backward()
 assert torch.allclose(xl.grad, w.expand(n, 16))
+# the pipelined form: asynchronous slices left pending, consumed by the column-side GEMM as they land, then the
+# reduce-scatter adjoint; the operand bound's MAX-reduce on the fp32 device scalar the GEMMs read
+from edgedisentangle_ssl_amd import ops_gemm
+xw = ic.features(5, n, 64).to(dev)
+w64 = (ic.features(6, 64, 256).to(dev) * 0.1).requires_grad_(True)
+xp = xw.clone().requires_grad_(True)
+xg = parallel._AllGatherRows.apply(xp, dg.counts, None, 3, True)
+pend = parallel.pending_of(xg)
+assert pend is not None and len(pend.slices) == 3
+amax = parallel.all_reduce_max(ops_gemm.amax(xp.detach()), dg)
+q = parallel.project_gathered(xg, w64, amax)
+assert parallel.pending_of(xg) is None
+ref_q = xw.double() @ w64.detach().double()
+assert float((q.detach().double() - ref_q).abs().max()) <= 2e-6 * float(ref_q.abs().max())
+q.sum().backward()
+assert torch.allclose(xp.grad, w64.detach().sum(1).expand(n, 64), rtol=1e-5, atol=1e-5)
+xg2 = parallel._AllGatherRows.apply(xw, dg.counts, None, 4, True)
+assert torch.equal(parallel.finish(xg2), xw) and parallel.pending_of(xg2) is None
 # the list form of all-gather (what ragged, nnz-balanced ranges use)
 bufs = [torch.empty_like(x)]
 dist.all_gather(bufs, x)

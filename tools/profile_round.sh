@@ -38,6 +38,11 @@ run att2_sq1 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY
 run att2_fetch --pmc FETCH_SIZE --output-format csv -d "$OUT/att2_fetch" -- $K2 &&
 run att2_write --pmc WRITE_SIZE --output-format csv -d "$OUT/att2_write" -- $K2 &&
 run att2_sq2 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_INST_LDS --output-format csv -d "$OUT/att2_sq2" -- $K2
+# the training step's backward kernels (seg_grad_sign, bwd_alpha, the weight-gradient GEMM): counters over one C4 training run
+T="python3 $ROOT/tools/train_bench.py --nodes 1000000 --edges 20000000"
+run train_fetch --pmc FETCH_SIZE --output-format csv -d "$OUT/train_fetch" -- $T &&
+run train_write --pmc WRITE_SIZE --output-format csv -d "$OUT/train_write" -- $T &&
+run train_sq1 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d "$OUT/train_sq1" -- $T
 echo "[profile] done"; date +%T
 # keep what travels back small (gpurun merges at most 64 MiB): the per-dispatch traces are not needed (the stats files
 # are), and of the per-dispatch counter rows only this library's kernels are

@@ -145,6 +145,38 @@ def main(src, dst):
             if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs and dur:
                 by = (2 * cs["FETCH_SIZE"] + cs["WRITE_SIZE"]) * 1024
                 P(f"\nHBM bytes per launch (2 x FETCH + WRITE): {by / 1e9:.2f} GB -> {by / (dur * 1e-3) / 1e12:.2f} TB/s moved")
+    if os.path.isdir(os.path.join(src, "train_fetch")):
+        with open(os.path.join(dst, "train_pmc.md"), "w") as out:
+            P = lambda *a: print(*a, file=out)      # noqa: E731
+            P("# Training step (tools/train_bench.py, C4: 1M nodes / 20M edges, F = 256, H = 8, att 3, dropout 0.1): PMC counters of the backward kernels\n")
+            P("Per-launch averages, one row per (kernel, grid size): the 20M-edge lists and the 66.5M-pair lists share kernels.  Durations "
+              "are the dispatch timestamps of the FETCH_SIZE pass (kernels serialised by the profiler; `kt_c4_train_summary.md` has the "
+              "untraced averages per kernel name).  Separate rocprofv3 passes: FETCH_SIZE, "
+              "WRITE_SIZE, SQ set.  HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes; gfx950 correction as in kt_c4_att3_summary.md).\n")
+            vals, calls, durs = {}, {}, {}
+            for sub in ("fetch", "write", "sq1"):
+                for f in newest(os.path.join(src, f"train_{sub}", "*", "*_counter_collection.csv")):
+                    for r in csv.DictReader(open(f)):
+                        if "disgat" not in r["Kernel_Name"]:
+                            continue
+                        k = (r["Kernel_Name"].split("(")[0], int(r["Grid_Size"]))
+                        vals.setdefault(k, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+                        if sub == "fetch":
+                            durs.setdefault(k, []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+            P("| kernel | grid (threads) | launches | avg ms (FETCH pass) | HBM GB / launch | TB/s moved | issuing % | issue-stalled % | parked % |\n|---|---|---|---|---|---|---|---|---|")
+            rows = []
+            for k, cs in vals.items():
+                cs = {c: sum(v) / len(v) for c, v in cs.items()}
+                d = durs.get(k)
+                dur = sum(d) / len(d) if d else None
+                by = (2 * cs.get("FETCH_SIZE", 0) + cs.get("WRITE_SIZE", 0)) * 1024
+                w = cs.get("SQ_WAVE_CYCLES", 0)
+                pct = [f"{cs.get(c, 0) / w * 100:.0f}" if w else "-" for c in ("SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY")]
+                rows.append(((dur or 0) * len(d or []), f"| `{k[0][:80]}` | {k[1]} | {len(d or [])} | " + (f"{dur:.3f}" if dur else "-") + f" | {by / 1e9:.2f} | "
+                             + (f"{by / (dur * 1e-3) / 1e12:.2f}" if dur else "-") + " | " + " | ".join(pct) + " |"))
+            for _t, line in sorted(rows, reverse=True)[:24]:
+                P(line)
+        print(open(os.path.join(dst, "train_pmc.md")).read())
     print(open(os.path.join(dst, "att2_pmc.md")).read())
     print(open(os.path.join(dst, "gemm_f16x3_pmc.md")).read())
     print(open(os.path.join(dst, "kt_c4_att3_summary.md")).read())
