@@ -87,14 +87,14 @@ _SIGS = {
     "disgat_last_error": (_c.c_char_p, []),
     "disgat_edge_fwd": (_c.c_int, [_c.c_int, _P, _c.c_int, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
                                    _P, _c.c_int, _P, _c.c_int, _P, _c.c_int, _P, _P, _P, _P, _P, _P, _c.c_int,
-                                   _c.c_float, _c.c_uint64, _P, _P, _P, _P, _P, _P]),
+                                   _c.c_float, _c.c_uint64, _P, _P, _P, _P, _P, _P, _P]),
     "disgat_edge_combine": (_c.c_int, [_P, _P, _c.c_int, _c.c_int, _c.c_int, _P, _P, _P, _P, _c.c_int, _P, _P, _P, _P]),
     "disgat_aux_score": (_c.c_int, [_c.c_int, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
                                     _c.c_int, _P, _c.c_int, _P, _c.c_int, _P, _c.c_int, _P, _P, _P, _P]),
     "disgat_pair_loss": (_c.c_int, [_P, _c.c_int64, _c.c_int, _c.c_int, _P, _P, _P, _P]),
     "disgat_pair_loss_bwd": (_c.c_int, [_P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _P, _P, _P, _P]),
     "disgat_bwd_alpha": (_c.c_int, [_P, _c.c_int, _P, _c.c_int64, _c.c_int, _c.c_int, _P, _c.c_int, _P, _P, _P, _P, _P,
-                                    _P, _P, _c.c_int, _c.c_float, _c.c_uint64, _P]),
+                                    _P, _P, _c.c_int, _c.c_float, _c.c_uint64, _P, _P]),
     "disgat_seg_grad_att3": (_c.c_int, [_P, _c.c_int, _P, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
                                         _P, _c.c_int, _P, _c.c_int, _P, _P, _c.c_int, _P, _c.c_int, _P, _P]),
     "disgat_seg_grad_sign": (_c.c_int, [_P, _c.c_int, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P,
@@ -123,6 +123,7 @@ _SIGS = {
     "disgat_amax": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _P, _P]),
     "disgat_act_bwd": (_c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int, _c.c_float, _P, _P]),
     "disgat_adam_multi": (_c.c_int, [_c.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _c.c_double, _c.c_double, _c.c_float, _P]),
+    "disgat_adam_multi_dev": (_c.c_int, [_c.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _c.c_double, _c.c_double, _c.c_float, _P]),
 }
 
 

@@ -39,3 +39,110 @@ def capture_get_em(encoder, x, adj, fusers):
     g = graph_of(adj)
     encoder.eval()
     return CapturedCall(lambda feats: encoder.get_em(feats, g, fusers), x)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Whole train_steps as HIP graphs.  On Cora / chameleon a train_step is ~400 launches of a few microseconds each
+# behind ~7 ms of Python + autograd-engine work; replayed from a graph, the host does three things per step: one
+# binomial draw per pair list (written into a device scalar), the replay call, and the bookkeeping of step counts.
+# What makes a step replayable:
+#   * pair lists of FIXED capacity, sampled on the device with their valid length on the device
+#     (sampling.StaticSampler; padding carries label -1, which disgat_pair_loss / _bwd skip);
+#   * backward segment structures built without reading sizes back (ops_bwd._segments_static);
+#   * attention-dropout seeds = a per-call-site constant + a device counter the step advances (layers.StepSeed);
+#   * Adam's step counts on the device (optim.DeviceStepAdam / disgat_adam_multi_dev).
+# The first call runs the step eagerly a few times to build every cache (CSR transpose, work items, hipBLASLt
+# workspaces), ROLLS the trainer BACK to where it started (parameters, Adam moments and counts, seed counter, RNG
+# streams), captures, and from then on replays - so step 1 of the run already comes from the graph and a captured
+# run follows the same trajectory as the same static step run eagerly (tests/test_gpu_capture.py).
+class StaticStep:
+    def __init__(self, trainer, host_fn, device_fn, warmup=2):
+        from . import layers, optim
+        self.trainer, self.host_fn, self.device_fn, self.warmup = trainer, host_fn, device_fn, warmup
+        dev = next(trainer.models[0].parameters()).device
+        self.seed = layers.StepSeed(dev)
+        self.adam = optim.DeviceStepAdam(trainer.models_opt)
+        self.graph = None
+        self.logs = None
+        self.replays = 0
+
+    # -- one execution of the step's device half (eager or under capture)
+    def _body(self, *args):
+        from . import layers
+        tr = self.trainer
+        tr._begin_step()
+        prev, layers.STEP_SEED = layers.STEP_SEED, self.seed
+        try:
+            self.seed.begin_step()
+            return self.device_fn(self.adam, *args)
+        finally:
+            layers.STEP_SEED = prev
+
+    def run_eager(self, *args):
+        """The static step without a graph (reference behaviour of the captured one; also the warm-up)."""
+        self.host_fn(*args)
+        self.adam.sync()
+        logs = self._body(*args)
+        self.adam.advance_host()
+        return logs
+
+    def _snapshot(self):
+        tr = self.trainer
+        params = [p for m in tr.models for p in m.parameters()]
+        opt = []
+        for o in tr.models_opt:
+            opt.append({id(p): (st[0], st[1].clone(), st[2].clone()) for p in o.params for st in [o.state.get(id(p))] if st is not None})
+        return dict(params=[(p, p.detach().clone()) for p in params], opt=opt, seed=self.seed.counter.clone(),
+                    cpu_rng=torch.get_rng_state(), cuda_rng=torch.cuda.get_rng_state())
+
+    def _restore(self, snap):
+        tr = self.trainer
+        with torch.no_grad():
+            for p, v in snap["params"]:
+                p.copy_(v)
+            for o, saved in zip(tr.models_opt, snap["opt"]):
+                for p in o.params:
+                    st = o.state.get(id(p))
+                    if st is None:
+                        continue
+                    old = saved.get(id(p))
+                    if old is None:                  # created by the warm-up: back to a fresh state, same tensors
+                        st[0] = 0
+                        st[1].zero_()
+                        st[2].zero_()
+                    else:
+                        st[0] = old[0]
+                        st[1].copy_(old[1])
+                        st[2].copy_(old[2])
+            self.seed.counter.copy_(snap["seed"])
+        torch.set_rng_state(snap["cpu_rng"])
+        torch.cuda.set_rng_state(snap["cuda_rng"])
+
+    def _capture(self, *args):
+        snap = self._snapshot()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(self.warmup):
+                self.run_eager(*args)
+        torch.cuda.current_stream().wait_stream(side)
+        self._restore(snap)
+        self.host_fn(*args)             # the capture pass itself consumes no host randomness that a replay would not
+        self.adam.sync()
+        for o in self.trainer.models_opt:
+            o.zero_grad()
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.logs = self._body(*args)
+        self._restore(snap)             # the host generator again: the first replay draws what an uncaptured first step would
+
+    def __call__(self, *args):
+        if self.graph is None:
+            self._capture(*args)
+        self.host_fn(*args)
+        self.adam.sync()
+        self.graph.replay()
+        self.adam.advance_host()
+        self.replays += 1
+        return self.logs

@@ -236,6 +236,7 @@ __global__ __launch_bounds__(256) void aux_att1_kernel(const AuxArgs A) {
 // pred = sigmoid(sum_{h in [h_lo,h_hi)} aux[h][m]); squared error against 0/1 labels, split by
 // label so the host can apply adj_mse_loss's class weights (utils.py:287-298):
 //   acc[0] += sum_{t!=0} (pred-t)^2, acc[1] += sum_{t==0} (pred-t)^2, acc[2] += #{t!=0}
+// Entries with a negative label are padding (fixed-capacity lists of captured steps): skipped here, zero gradient below.
 __global__ __launch_bounds__(256) void pair_loss_kernel(const float* __restrict__ aux, int64_t M, int h_lo, int h_hi,
                                                         const float* __restrict__ labels, double* __restrict__ part) {
   double sp = 0.0, sn = 0.0, np_ = 0.0;
@@ -244,6 +245,7 @@ __global__ __launch_bounds__(256) void pair_loss_kernel(const float* __restrict_
     float s = 0.f;
     for (int h = h_lo; h < h_hi; ++h) s += aux[(int64_t)h * M + m];
     const float t = labels[m];
+    if (t < 0.f) continue;                     // padding of a fixed-capacity list: in no sum
     const float d = sigmoidf_(s) - t;
     if (t != 0.f) {
       sp += (double)(d * d);
@@ -291,7 +293,7 @@ __global__ __launch_bounds__(256) void pair_loss_bwd_kernel(const float* __restr
     for (int h = h_lo; h < h_hi; ++h) s += aux[(int64_t)h * M + m];
     const float t = labels[m];
     const float p = sigmoidf_(s);
-    const float gv = (t != 0.f ? c_pos : c_neg) * 2.0f * (p - t) * p * (1.0f - p);
+    const float gv = t < 0.f ? 0.f : (t != 0.f ? c_pos : c_neg) * 2.0f * (p - t) * p * (1.0f - p);   // t < 0: padding
     for (int h = 0; h < H; ++h) g[(int64_t)h * M + m] = (h >= h_lo && h < h_hi) ? gv : 0.f;
   }
 }

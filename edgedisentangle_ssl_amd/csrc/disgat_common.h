@@ -153,15 +153,18 @@ __device__ __forceinline__ float dot4(const f32x4 a, const f32x4 b, float acc) {
 // Attention dropout (layers.py:394: F.dropout on the normalised attention, training only).
 // Counter-based: one splitmix64 hash of (seed, edge*H + head); keep iff the top 32 bits >= thresh
 // (thresh = p * 2^32).  Returns the multiplier mask/(1-p).  Forward and backward regenerate the
-// same mask from the same (seed, edge, head).
+// same mask from the same (seed, edge, head).  seed_dev (or NULL): a device counter added to the seed - a step captured
+// in a HIP graph bakes `seed` in, so the per-step variation comes from memory the graph advances itself.
 struct DropCfg {
   uint64_t seed;
   uint32_t thresh;   // 0 = dropout off
   float scale;       // 1/(1-p)
+  const uint64_t* seed_dev;
 };
 __device__ __forceinline__ float drop_mult(const DropCfg& d, int64_t k, int h, int H) {
   if (d.thresh == 0u) return 1.0f;
-  uint64_t z = d.seed + (uint64_t)(k * H + h) * 0x9E3779B97F4A7C15ull;
+  const uint64_t seed = d.seed + (d.seed_dev ? *d.seed_dev : 0ull);        // wave-uniform: one scalar load, hoisted
+  uint64_t z = seed + (uint64_t)(k * H + h) * 0x9E3779B97F4A7C15ull;
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
   z ^= z >> 31;

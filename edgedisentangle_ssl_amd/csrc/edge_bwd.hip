@@ -506,7 +506,7 @@ __global__ __launch_bounds__(256) void seg_combine_kernel(const int32_t* __restr
 extern "C" int disgat_bwd_alpha(const int32_t* items, int n_items, const int32_t* col, int64_t E, int H, int F_in,
                                 const float* x, int ldx, const float* gZ, const float* Z, const float* edge_e,
                                 const float* den, const float* ge_in, float* ge_out, float* beta, int sage_div,
-                                float drop_p, uint64_t drop_seed, disgat_stream_t stream) {
+                                float drop_p, uint64_t drop_seed, const uint64_t* drop_seed_dev, disgat_stream_t stream) {
   using namespace disgat;
   if (n_items == 0 || E == 0) return 0;
   const int hl = ilog2_exact(H);
@@ -517,7 +517,7 @@ extern "C" int disgat_bwd_alpha(const int32_t* items, int n_items, const int32_t
   DISGAT_REQUIRE(xn == 1 || (xn == 2 && hl <= 3), "bwd_alpha: F_in=%d too wide for H=%d", F_in, H);
   BwdAlphaArgs A{reinterpret_cast<const int4*>(items), n_items, col, E, F_in, x, ldx, gZ, Z, edge_e, den, ge_in,
                  ge_out, beta, sage_div,
-                 DropCfg{drop_seed, (uint32_t)((double)drop_p * 4294967296.0), 1.0f / (1.0f - drop_p)}};
+                 DropCfg{drop_seed, (uint32_t)((double)drop_p * 4294967296.0), 1.0f / (1.0f - drop_p), drop_seed_dev}};
   const dim3 grid((n_items + DISGAT_WAVES_PER_BLOCK - 1) / DISGAT_WAVES_PER_BLOCK), block(DISGAT_BLOCK);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 #define DISGAT_BA(HL_, XN_) hipLaunchKernelGGL((bwd_alpha_kernel<HL_, XN_>), grid, block, 0, s, A)

@@ -404,7 +404,7 @@ extern "C" int disgat_edge_fwd(int att, const int32_t* items, int n_items, const
                                int F_in, int F_out, const float* x, int ldx, const float* rowop, int ld_row,
                                const float* colop, int ld_col, const float* a, float* Z, float* edge_e, float* den,
                                float* part_z, float* part_den, int sage_div, float drop_p, uint64_t drop_seed,
-                               uint32_t* sign_bits, const float* e_in, uint16_t* Z_hi, uint16_t* Z_lo, const float* z_bound,
+                               const uint64_t* drop_seed_dev, uint32_t* sign_bits, const float* e_in, uint16_t* Z_hi, uint16_t* Z_lo, const float* z_bound,
                                disgat_stream_t stream) {
   using namespace disgat;
   DISGAT_REQUIRE(att >= 1 && att <= 4, "edge_fwd: att=%d not in 1..3 (4 = att 2 over projected operands)", att);
@@ -434,7 +434,7 @@ extern "C" int disgat_edge_fwd(int att, const int32_t* items, int n_items, const
   }
   EdgeFwdArgs args{reinterpret_cast<const int4*>(items), n_items, col, E, N, F_in, x, ldx, rowop, ld_row, colop, ld_col,
                    a, Z, edge_e, den, part_z, part_den, sage_div,
-                   DropCfg{drop_seed, (uint32_t)((double)drop_p * 4294967296.0), 1.0f / (1.0f - drop_p)},
+                   DropCfg{drop_seed, (uint32_t)((double)drop_p * 4294967296.0), 1.0f / (1.0f - drop_p), drop_seed_dev},
                    att == 3 ? sign_bits : nullptr, e_in, Z_hi, Z_lo, z_bound};
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   switch (att) {

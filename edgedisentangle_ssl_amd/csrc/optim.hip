@@ -18,13 +18,22 @@ struct AdamArgs {                   // passed by value in the kernel arguments (
   float* v[kMaxTensors];
   int n[kMaxTensors];
   int first_block[kMaxTensors + 1];
-  float step_size[kMaxTensors];     // lr / (1 - beta1^t)
-  float inv_sqrt_bc2[kMaxTensors];  // 1 / sqrt(1 - beta2^t)
+  union alignas(8) {
+    struct {
+      float step_size[kMaxTensors];     // lr / (1 - beta1^t)
+      float inv_sqrt_bc2[kMaxTensors];  // 1 / sqrt(1 - beta2^t)
+    };
+    double lr[kMaxTensors];             // DEV: the plain learning rate (the corrections are formed in the kernel)
+  };
   float wd[kMaxTensors];
   int count;
 };
 
-__global__ __launch_bounds__(256) void adam_multi_kernel(const AdamArgs a, float omb1, float beta2, float omb2, float eps) {
+// DEV: the step counts live on the device (steps[t], already advanced): what a train_step captured in a HIP graph needs -
+// the host-side corrections of the eager form would be baked into the graph.  Same double arithmetic as the host's.
+template <bool DEV>
+__global__ __launch_bounds__(256) void adam_multi_kernel(const AdamArgs a, float omb1, float beta2, float omb2, float eps,
+                                                         const int* __restrict__ steps, double beta1_d, double beta2_d) {
   // block -> tensor: binary search over <= 64 prefix entries (uniform per block: scalar registers)
   int lo = 0, hi = a.count;
   const int b = blockIdx.x;
@@ -39,7 +48,16 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const AdamArgs a, float
   const float* __restrict__ g = a.g[t];
   float* __restrict__ m = a.m[t];
   float* __restrict__ v = a.v[t];
-  const float ss = a.step_size[t], ib = a.inv_sqrt_bc2[t], wd = a.wd[t];
+  float ss, ib;
+  if constexpr (DEV) {
+    const double tt = (double)steps[t];
+    ss = (float)(a.lr[t] / (1.0 - pow(beta1_d, tt)));
+    ib = (float)(1.0 / sqrt(1.0 - pow(beta2_d, tt)));
+  } else {
+    ss = a.step_size[t];
+    ib = a.inv_sqrt_bc2[t];
+  }
+  const float wd = a.wd[t];
   auto upd = [&](float& pw, float gw, float& mw, float& vw) {
     gw = fmaf(wd, pw, gw);                       // grad = grad + wd * param
     mw = mw + (gw - mw) * omb1;                  // exp_avg.lerp_(grad, 1 - beta1)
@@ -79,10 +97,10 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const AdamArgs a, float
 
 }  // namespace
 
-extern "C" int disgat_adam_multi(int count, float* const* params, const float* const* grads, float* const* exp_avg,
-                                 float* const* exp_avg_sq, const int64_t* numel, const float* step_size,
-                                 const float* inv_sqrt_bc2, const float* weight_decay, double beta1, double beta2,
-                                 float eps, disgat_stream_t stream) {
+static int adam_launch(int count, float* const* params, const float* const* grads, float* const* exp_avg,
+                       float* const* exp_avg_sq, const int64_t* numel, const float* step_size, const float* inv_sqrt_bc2,
+                       const double* lr, const float* weight_decay, const int32_t* steps, double beta1, double beta2,
+                       float eps, disgat_stream_t stream) {
   DISGAT_REQUIRE(count >= 0, "adam_multi: negative tensor count");
   const double beta1_d = beta1, beta2_d = beta2;
   for (int off = 0; off < count; off += kMaxTensors) {
@@ -100,17 +118,43 @@ extern "C" int disgat_adam_multi(int count, float* const* params, const float* c
       a.v[i] = exp_avg_sq[off + i];
       a.n[i] = (int)n;
       a.first_block[i] = blocks;
-      a.step_size[i] = step_size[off + i];
-      a.inv_sqrt_bc2[i] = inv_sqrt_bc2[off + i];
+      if (steps) {
+        a.lr[i] = lr[off + i];
+      } else {
+        a.step_size[i] = step_size[off + i];
+        a.inv_sqrt_bc2[i] = inv_sqrt_bc2[off + i];
+      }
       a.wd[i] = weight_decay[off + i];
       blocks += (int)((n + kChunk - 1) / kChunk);
     }
     a.first_block[a.count] = blocks;
     if (blocks == 0) continue;
     // 1 - beta in double, as torch forms the lerp / addcmul weights (1.0f - 0.999f is off by 1.3e-5 relative)
-    hipLaunchKernelGGL(adam_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, (float)(1.0 - (double)beta1_d),
-                       (float)beta2_d, (float)(1.0 - beta2_d), eps);
+    if (steps)
+      hipLaunchKernelGGL(adam_multi_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, (float)(1.0 - beta1_d),
+                         (float)beta2_d, (float)(1.0 - beta2_d), eps, steps + off, beta1_d, beta2_d);
+    else
+      hipLaunchKernelGGL(adam_multi_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, (float)(1.0 - beta1_d),
+                         (float)beta2_d, (float)(1.0 - beta2_d), eps, (const int*)nullptr, beta1_d, beta2_d);
     if (int rc = disgat::check_launch("adam_multi")) return rc;
   }
   return 0;
+}
+
+extern "C" int disgat_adam_multi(int count, float* const* params, const float* const* grads, float* const* exp_avg,
+                                 float* const* exp_avg_sq, const int64_t* numel, const float* step_size,
+                                 const float* inv_sqrt_bc2, const float* weight_decay, double beta1, double beta2,
+                                 float eps, disgat_stream_t stream) {
+  DISGAT_REQUIRE(count == 0 || (step_size && inv_sqrt_bc2 && weight_decay && numel), "adam_multi: null table");
+  return adam_launch(count, params, grads, exp_avg, exp_avg_sq, numel, step_size, inv_sqrt_bc2, nullptr, weight_decay, nullptr,
+                     beta1, beta2, eps, stream);
+}
+
+extern "C" int disgat_adam_multi_dev(int count, float* const* params, const float* const* grads, float* const* exp_avg,
+                                     float* const* exp_avg_sq, const int64_t* numel, const double* lr,
+                                     const float* weight_decay, const int32_t* steps, double beta1, double beta2, float eps,
+                                     disgat_stream_t stream) {
+  DISGAT_REQUIRE(count == 0 || (lr && weight_decay && numel && steps), "adam_multi_dev: null table");
+  return adam_launch(count, params, grads, exp_avg, exp_avg_sq, numel, nullptr, nullptr, lr, weight_decay, steps, beta1, beta2,
+                     eps, stream);
 }

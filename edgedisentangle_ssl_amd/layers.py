@@ -289,6 +289,29 @@ def _no_graph(layers, x):
     return not (torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for l in layers for p in l.parameters())))
 
 
+class StepSeed:
+    """Attention-dropout seeds of a train_step that must replay from a HIP graph: the host part of a seed is fixed per
+    call site (the k-th disga_heads call of the step), the per-step variation is a device counter the step advances itself
+    (disgat_edge_fwd / disgat_bwd_alpha add it to the seed when they run).  The counter starts from torch's CPU generator,
+    so torch.manual_seed still repeats a run."""
+    GOLDEN = 0x9E3779B97F4A7C15 - (1 << 64)        # as a signed 64-bit addend
+
+    def __init__(self, device):
+        self.counter = torch.randint(0, 2 ** 62, (1,)).to(device)          # int64 storage, read as uint64 by the kernels
+        self.site = 0
+
+    def begin_step(self):
+        self.counter.add_(self.GOLDEN)         # wraps in two's complement = the uint64 sum the kernels form
+        self.site = 0
+
+    def next_site(self):
+        self.site += 1
+        return (self.site * 0xD1B54A32D192ED03) & (2 ** 62 - 1)
+
+
+STEP_SEED = None       # set by capture.StaticStep around a step's forward + backward
+
+
 def disga_heads(layers, x, adj, aux_indices=None, head_ranges=None, aux_only=False, heads_planes=False):
     """All H heads of one DISGAT layer: the loop of models.py:225-228 as ONE fused edge pass.
 
@@ -313,7 +336,10 @@ def disga_heads(layers, x, adj, aux_indices=None, head_ranges=None, aux_only=Fal
     if l0.training and l0.dropout > 0:
         # attention dropout (layers.py:394) is generated inside the kernel from a counter-based hash;
         # the seed comes from torch's CPU generator, so torch.manual_seed makes runs repeatable.
-        drop = (float(l0.dropout), int(torch.randint(0, 2 ** 62, (1,)).item()))
+        if STEP_SEED is not None:      # a step that may be captured in a HIP graph (capture.StaticStep): see StepSeed
+            drop = (float(l0.dropout), STEP_SEED.next_site(), STEP_SEED.counter)
+        else:
+            drop = (float(l0.dropout), int(torch.randint(0, 2 ** 62, (1,)).item()))
     graph = graph_of(adj)
     if graph.n != x.shape[0]:
         raise ValueError("adjacency / feature row count mismatch")

@@ -14,7 +14,10 @@ import torch
 
 from . import data_load, models, pretrainer, trainer
 from .features import surrogate_features
+from .graph import graph_of
 from .utils import get_parser, resolve_logs
+
+CAPTURE_MAX_EDGES = 2_000_000     # --capture auto: above this a step is kernel-bound and the eager path's load balancing matters
 
 SSL = {"DisEdge": pretrainer.GeneratedEdgeTrainer, "SupEdge": pretrainer.SupEdgeTrainer, "DifHead": pretrainer.DifHeadTrainer}
 
@@ -61,6 +64,9 @@ def run(argv=None, log=print):
     parser.add_argument("--data_root", type=str, default="data")
     parser.add_argument("--fixture", type=str, default=None)
     parser.add_argument("--quiet", action="store_true", default=False)
+    parser.add_argument("--capture", choices=("auto", "on", "off"), default="auto",
+                        help="replay every train_step from a HIP graph (capture.StaticStep); auto = one process and a graph "
+                             "of at most CAPTURE_MAX_EDGES edges, where a step is launch-bound")
     args = parser.parse_args(argv)
     if args.model != "DISGAT":
         raise SystemExit("only --model=DISGAT is implemented by this package (SURVEY 2: other encoders out of scope)")
@@ -145,6 +151,13 @@ def run(argv=None, log=print):
 
     if world > 1:
         reseed_rank(args.seed, rank)
+    captured = args.capture == "on" or (args.capture == "auto" and world == 1
+                                        and all(graph_of(a).nnz <= CAPTURE_MAX_EDGES for a in adjs))
+    if captured and world > 1:
+        raise SystemExit("--capture on: captured steps run on one process (the sharded step holds collectives)")
+    if captured:
+        adjs = [graph_of(a) for a in adjs]               # the same objects every step: a captured step replays on them
+    data_of = {}                                         # one [features, adj] list per adjacency, for the same reason
     history = []
     t0 = time.time()
     for epoch in range(args.epochs):                                      # main.py:270-360
@@ -163,10 +176,16 @@ def run(argv=None, log=print):
         if args.finetune:
             for _ in range(args.steps):
                 for tr in down:
-                    log_ep.update(tr.train_step([features, adj], labels, epoch))
+                    if captured:
+                        log_ep.update(tr.train_step_captured(data_of.setdefault(id(adj), [features, adj]), labels))
+                    else:
+                        log_ep.update(tr.train_step([features, adj], labels, epoch))
         for i, tr in enumerate(ssl_trainers):
             a = adjs[args.pre_edge[i] - 1]
-            log_ep.update(tr.train_step([features, a], ssl_labels[i]))
+            if captured:
+                log_ep.update(tr.train_step_captured(data_of.setdefault(id(a), [features, a]), ssl_labels[i]))
+            else:
+                log_ep.update(tr.train_step([features, a], ssl_labels[i]))
         log_ep = resolve_logs(log_ep)                    # the step logs are device scalars: one transfer per epoch
         history.append(log_ep)
         if not args.quiet:

@@ -91,7 +91,7 @@ def edge_forward(graph: CSRGraph, att, H, F_in, F_out, x, rowop, colop, a, sage_
     """Launch disgat_edge_fwd (+ disgat_edge_combine for split rows).
 
     x [N, >=F_in] (row stride % 4 == 0), rowop/colop 2-D views with unit inner
-    stride, a [H*F_out] or None; drop = (p, seed) of the attention dropout; sign: optional
+    stride, a [H*F_out] or None; drop = (p, seed[, device uint64 counter added to the seed]) of the attention dropout; sign: optional
     sign_record(...) buffer the att-3 kernel fills; e_in: optional contiguous [H,E] partial scores added before the
     sigmoid.  z_bound: optional device scalar >= max |Z|: Z is then returned as ops_gemm.Planes (the two fp16 planes the
     f16x3 projection GEMM consumes, [N,H,F_in] each) instead of an fp32 tensor.
@@ -124,7 +124,7 @@ def edge_forward(graph: CSRGraph, att, H, F_in, F_out, x, rowop, colop, a, sage_
             att, _ptr(wi.items), wi.n_items, _ptr(graph.col), e, n, H, F_in, F_out,
               _ptr(x), x.stride(0), _ptr(rowop), rowop.stride(0), _ptr(colop), 0 if colop is None else colop.stride(0),
               _ptr(a), _ptr(z), _ptr(edge_e), _ptr(den), _ptr(part_z), _ptr(part_den), int(bool(sage_div)),
-              float(drop[0]), int(drop[1]), _ptr(sign), _ptr(e_in), _ptr(zh), _ptr(zl), _ptr(z_bound), st)
+              float(drop[0]), int(drop[1]), _ptr(drop[2] if len(drop) > 2 else None), _ptr(sign), _ptr(e_in), _ptr(zh), _ptr(zl), _ptr(z_bound), st)
     if wi.n_split:
         _lib.call("disgat_edge_combine", _ptr(wi.split_rows), _ptr(wi.split_ptr), wi.n_split, H, F_in,
                   _ptr(part_z), _ptr(part_den), _ptr(z), _ptr(den), int(bool(sage_div)), _ptr(zh), _ptr(zl), _ptr(z_bound), st)

@@ -97,7 +97,7 @@ def edge_backward(ctx, gz, ge, want_ge=False):
     beta = torch.empty((H, e), dtype=torch.float32, device=dev)
     _lib.call("disgat_bwd_alpha", wi.items.data_ptr(), wi.n_items, graph.col.data_ptr(), e, H, f_in, x.data_ptr(),
               x.stride(0), gz.data_ptr(), z.data_ptr(), edge_e.data_ptr(), den.data_ptr(), ops._ptr(ge), ge_tot.data_ptr(),
-              beta.data_ptr(), int(bool(sage)), float(drop[0]), int(drop[1]), ops._stream())
+              beta.data_ptr(), int(bool(sage)), float(drop[0]), int(drop[1]), ops._ptr(drop[2] if len(drop) > 2 else None), ops._stream())
     g_x = g_row = g_col = g_a = None
     t = twi = None
     sign = getattr(ctx, "sign", None)
@@ -156,7 +156,10 @@ def _segments_of(pairs, side, n_keys, chunk):
     hit = _SEG_CACHE.get(key)
     if hit is not None:
         return hit[1]
-    res = _segments(pairs[side], n_keys, chunk)
+    if getattr(pairs, "_disgat_static", False):
+        res = _segments_static(pairs[side], n_keys, side == 0)
+    else:
+        res = _segments(pairs[side], n_keys, chunk)
     if len(_SEG_CACHE) >= 8:
         _SEG_CACHE.pop(next(iter(_SEG_CACHE)))
     _SEG_CACHE[key] = (pairs, res)
@@ -174,6 +177,29 @@ def _segments(keys, n_keys, chunk):
         perm, perm32 = None, None
     ptr = torch.searchsorted(keys, torch.arange(n_keys + 1, device=keys.device, dtype=keys.dtype))
     return build_items(ptr, chunk), perm, perm32
+
+
+def _segments_static(keys, n_keys, is_sorted):
+    """_segments() for the fixed-capacity lists of captured steps (sampling.StaticSampler): no size is read back and every
+    shape is fixed - one work item per key whatever its length (no slices, so no partial records; on the small graphs this
+    path serves a key's segment is a few hundred entries), items in key order."""
+    from .graph import WorkItems
+    dev = keys.device
+    if is_sorted:
+        perm = perm32 = None
+    else:
+        perm = torch.sort(keys, stable=True).indices
+        keys = keys[perm]
+        perm32 = perm.to(torch.int32)
+    ptr = torch.searchsorted(keys, torch.arange(n_keys + 1, device=dev, dtype=keys.dtype)).to(torch.int32)
+    wi = WorkItems()
+    wi.items = torch.stack([torch.arange(n_keys, device=dev, dtype=torch.int32), ptr[:-1], ptr[1:],
+                            torch.full((n_keys,), -1, dtype=torch.int32, device=dev)], 1).contiguous()
+    wi.n_items = int(n_keys)
+    wi.n_split = wi.n_slots = 0
+    wi.split_rows = wi.split_ptr = torch.zeros(1, dtype=torch.int32, device=dev)
+    wi.chunk = None
+    return wi, perm, perm32
 
 
 def aux_backward(ctx, gout):
@@ -209,7 +235,7 @@ def aux_backward(ctx, gout):
             g_a = g_a + ga_c if need_a else None
         return g_x, g_row, g_col, g_a, None, None
     if need_row or need_a:
-        wi, perm, perm32 = _segments(rows, n_rows, chunk)
+        wi, perm, perm32 = _segments_of(pairs, 0, n_rows, chunk)
         other = (cols if perm is None else cols[perm]).to(torch.int32)
         if att == 4:
             g_row, _ = _seg_att3(wi, other, perm32, gout, lo, hi, H, f_out, rowop, colop, None, n_rows, False)
@@ -219,7 +245,7 @@ def aux_backward(ctx, gout):
             g_row = _keybuf((n_rows, H * f_in), dev, wi)
             _seg_hx(0, wi, other, perm32, gout, lo, hi, H, f_in, x, g_row, False)
     if (att in (3, 4) and need_col) or (att == 2 and need_x):
-        wi, perm, perm32 = _segments(cols, n_cols, chunk)
+        wi, perm, perm32 = _segments_of(pairs, 1, n_cols, chunk)
         other = (rows if perm is None else rows[perm]).to(torch.int32)
         if att in (3, 4):
             g_col, _ = _seg_att3(wi, other, perm32, gout, lo, hi, H, f_out, colop, rowop, a if att == 3 else None, n_cols, False)
@@ -260,7 +286,7 @@ def layer_backward_remat(ctx, gz, ge, gaux):
         beta = torch.empty((H, e), dtype=torch.float32, device=dev)
         _lib.call("disgat_bwd_alpha", wi.items.data_ptr(), wi.n_items, graph.col.data_ptr(), e, H, f_in, x.data_ptr(),
                   x.stride(0), gz.data_ptr(), z.data_ptr(), edge_e.data_ptr(), den.data_ptr(), ops._ptr(ge), ge_tot.data_ptr(),
-                  beta.data_ptr(), int(bool(sage)), float(drop[0]), int(drop[1]), ops._stream())
+                  beta.data_ptr(), int(bool(sage)), float(drop[0]), int(drop[1]), ops._ptr(drop[2] if len(drop) > 2 else None), ops._stream())
         t = graph.transpose()
         twi = t.work_items(chunk)
     g_x = g_row = g_col = g_a = None

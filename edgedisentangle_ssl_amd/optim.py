@@ -88,3 +88,93 @@ def step_all(optimisers):
         # the kernel wrote the parameters through raw pointers: advance autograd's version counters as an in-place
         # torch op would (saved-tensor checks and the packed-weight memo in layers._memo key on them)
         torch.autograd.graph.increment_version([e[0] for e in ent])
+
+
+class DeviceStepAdam:
+    """step_all() for a train_step that replays from a HIP graph: the step counts live in a device int32 tensor the step
+    advances itself and the kernel forms the bias corrections from them (disgat_adam_multi_dev) - the host-side
+    corrections of step_all() would be frozen into the graph at their capture-time values.  The host counts of the
+    ModuleAdam states stay the truth between modes: `sync()` loads them into the device tensor when they moved without
+    it (eager steps, a rolled-back warm-up, load_state_dict), `advance_host()` is called once per executed / replayed step."""
+
+    def __init__(self, optimisers):
+        self.optimisers = list(optimisers)
+        self.keys = None            # (optimiser index, param index) of every parameter that receives a gradient
+        self.steps = None
+        self.mirror = None
+
+    def _entries(self):
+        ent, keys = [], []
+        for oi, o in enumerate(self.optimisers):
+            for pi, p in enumerate(o.params):
+                g = p.grad
+                if g is None:
+                    continue
+                if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
+                    raise RuntimeError("DeviceStepAdam: parameters must be contiguous fp32 device tensors (no CPU fallback)")
+                if not g.is_contiguous():
+                    g = p.grad = g.contiguous()
+                st = o.state.get(id(p))
+                if st is None:
+                    st = o.state[id(p)] = [0, torch.zeros_like(p), torch.zeros_like(p)]
+                ent.append((p, g, st[1], st[2], o.lr, o.weight_decay, o, st))
+                keys.append((oi, pi))
+        return ent, keys
+
+    def host_steps(self, ent):
+        return [e[7][0] for e in ent]
+
+    def step(self):
+        """Enqueue: steps += 1, then one launch per (betas, eps) group.  No host state changes (see advance_host)."""
+        ent, keys = self._entries()
+        if self.keys is None:
+            self.keys = keys
+            dev = ent[0][0].device if ent else torch.device("cuda")
+            self.steps = torch.tensor(self.host_steps(ent), dtype=torch.int32, device=dev)
+            self.mirror = self.host_steps(ent)
+        elif keys != self.keys:
+            raise RuntimeError("DeviceStepAdam: the set of parameters with a gradient changed between steps of a captured trainer")
+        self._last = ent
+        if not ent:
+            return
+        self.steps.add_(1)
+        stream = torch.cuda.current_stream().cuda_stream
+        order = sorted(range(len(ent)), key=lambda i: (ent[i][6].betas, ent[i][6].eps))
+        if order != list(range(len(ent))):
+            raise RuntimeError("DeviceStepAdam: optimisers with different betas / eps must be listed in groups")
+        i = 0
+        while i < len(ent):
+            o0 = ent[i][6]
+            j = i
+            while j < len(ent) and (ent[j][6].betas, ent[j][6].eps) == (o0.betas, o0.eps):
+                j += 1
+            grp, n = ent[i:j], j - i
+            ptr = lambda k: (ctypes.c_void_p * n)(*[e[k].data_ptr() for e in grp])          # noqa: E731
+            numel = (ctypes.c_int64 * n)(*[e[0].numel() for e in grp])
+            lr = (ctypes.c_double * n)(*[e[4] for e in grp])
+            wd = (ctypes.c_float * n)(*[e[5] for e in grp])
+            with torch.no_grad():
+                _lib.call("disgat_adam_multi_dev", n, ptr(0), ptr(1), ptr(2), ptr(3), numel, lr, wd,
+                          self.steps.data_ptr() + 4 * i, o0.betas[0], o0.betas[1], o0.eps, stream)
+            i = j
+
+    def sync(self):
+        """Before a step runs or replays: make the device counts equal the host's if those moved on their own."""
+        if self.keys is None:
+            return
+        host = [self.optimisers[oi].state[id(self.optimisers[oi].params[pi])][0] for oi, pi in self.keys]
+        if host != self.mirror:
+            self.steps.copy_(torch.tensor(host, dtype=torch.int32))
+            self.mirror = host
+
+    def advance_host(self):
+        """After a step ran (eagerly or as a replay): the host counts follow, parameter versions advance."""
+        params = []
+        for oi, pi in self.keys or []:
+            o = self.optimisers[oi]
+            p = o.params[pi]
+            o.state[id(p)][0] += 1
+            params.append(p)
+        self.mirror = [m + 1 for m in self.mirror] if self.mirror is not None else None
+        if params:
+            torch.autograd.graph.increment_version(params)

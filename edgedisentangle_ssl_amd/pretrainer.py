@@ -45,7 +45,10 @@ def _sample(graph, pos, n_pos_global):
 def _pair_loss_value(base, h_lo, h_hi, labels, graph):
     """(loss, neg_w, m) from the HIP partial sums; on a sharded graph sums and pair count are all-reduced (global loss)."""
     acc = ops.pair_loss_sums(base, h_lo, h_hi, labels)
-    acc = torch.cat([acc, acc.new_full((1,), float(labels.shape[0]))])     # fill kernel: stays graph-capturable
+    count = getattr(labels, "_disgat_count", None)      # fixed-capacity list (sampling.StaticSampler): its valid length, on the device
+    if count is None:
+        count = acc.new_full((1,), float(labels.shape[0]))                 # fill kernel: stays graph-capturable
+    acc = torch.cat([acc, count.reshape(1).to(acc.dtype)])
     parallel.all_reduce_sum(acc, graph)
     m = acc[3]
     neg_w = acc[2] / (m * m - acc[2])
@@ -135,6 +138,34 @@ class Trainer(object):
     def _layer_on(self, i):
         return self.constrain_layer == 0 or self.constrain_layer == i       # pretrainer.py:597, 728
 
+    # ---- the same train_step as a HIP graph (capture.StaticStep): subclasses give the host half (_static_host: the
+    # sampler's binomial draws) and the device half (_static_device: sample + forward + loss + backward + Adam).
+    def _static_finish(self, adam, loss, always_step=False):
+        (loss * self.loss_weight).backward()
+        ops_bwd.clear_segment_cache()
+        if self.loss_weight != 0 or always_step:
+            adam.step()
+
+    def static_step(self):
+        from .capture import StaticStep
+        st = self.__dict__.get("_static")
+        if st is None:
+            st = self._static = StaticStep(self, self._static_host, self._static_device)
+        return st
+
+    def train_step_captured(self, *args):
+        """train_step replayed from a HIP graph (unsharded graphs; the arguments must be the same objects every call).
+        Returns the step's log dict - 0-d device tensors that the NEXT replay overwrites."""
+        st = self.static_step()
+        flat = [b for a in args for b in (a if isinstance(a, (list, tuple)) else [a])]
+        key = tuple(id(a) for a in flat if not isinstance(a, (int, float, type(None))))
+        if st.__dict__.setdefault("_args_key", key) != key:
+            raise RuntimeError("train_step_captured: a captured step replays on the tensors it was captured with")
+        return st(*args)
+
+    def _static_host(self, *args):
+        pass
+
     def analyze_disentangle(self, feature, adj):
         """trainer.py:82-134: how different are the heads?  Per layer: the head x head correlation of the raw scores
         on a sampled pair list (a third of the edges + 3x as many random pairs), its mean absolute value, and the
@@ -202,6 +233,22 @@ class SupEdgeTrainer(Trainer):
         labels, indices = self.sample_train(gt_adj if gt_adj is not None else data[1])
         loss = self.loss(data, labels, indices)
         self._finish_step(loss, graph_of(data[1]))
+        return {"loss_heads_sup": loss.detach()}
+
+    def _static_sampler(self, gt):
+        g = graph_of(gt)
+        smp = g.__dict__.get("_static_sampler")
+        if smp is None:
+            smp = g._static_sampler = sampling.StaticSampler(g.n, sampling.flat_edges(g), n_cols=g.n_cols)
+        return smp
+
+    def _static_host(self, data, gt_adj=None):
+        self._static_sampler(gt_adj if gt_adj is not None else data[1]).draw_k()
+
+    def _static_device(self, adam, data, gt_adj=None):
+        indices, labels = self._static_sampler(gt_adj if gt_adj is not None else data[1]).sample()
+        loss = self.loss(data, labels, [indices])
+        self._static_finish(adam, loss)
         return {"loss_heads_sup": loss.detach()}
 
 
@@ -273,6 +320,21 @@ class GeneratedEdgeTrainer(Trainer):
         adj_labels, adj_masks = self.sample_train()
         loss = self.loss(data, adj_labels, adj_masks)
         self._finish_step(loss, graph_of(data[1]))
+        return {"loss_head_disen": loss.detach()}
+
+    def _static_samplers(self):
+        if self.__dict__.get("_samplers") is None:
+            self._samplers = [sampling.StaticSampler(self.graph.n, pos, n_cols=self.graph.n_cols) for pos in self.dis_adjs]
+        return self._samplers
+
+    def _static_host(self, data, pre_adjs=None):
+        for smp in self._static_samplers():
+            smp.draw_k()
+
+    def _static_device(self, adam, data, pre_adjs=None):
+        pairs = [smp.sample() for smp in self._static_samplers()]
+        loss = self.loss(data, [lab for _idx, lab in pairs], [idx for idx, _lab in pairs])
+        self._static_finish(adam, loss)
         return {"loss_head_disen": loss.detach()}
 
 
@@ -379,4 +441,9 @@ class DifHeadTrainer(Trainer):
         self._begin_step()
         loss = self.loss(data)
         self._finish_step(loss, graph_of(data[1]))
+        return {"loss_head_diversity": loss.detach()}
+
+    def _static_device(self, adam, data, pre_dif=None):
+        loss = self.loss(data)
+        self._static_finish(adam, loss)
         return {"loss_head_diversity": loss.detach()}

@@ -102,6 +102,19 @@ class ClsTrainer(Trainer):
             log["roc_val"], log["macroF_val"] = roc_f(output[self.idx_val], labels[self.idx_val])
         return log
 
+    def _static_device(self, adam, data, labels, epoch=0):
+        feature, adj = data
+        graph = graph_of(adj)
+        output = self.classifier(self.get_em(feature, adj), cls=True)
+        loss_log, acc_train = self._nll_acc(output, labels, self.idx_train, graph)
+        reg_log = self.reg_fuser()
+        loss = loss_log + reg_log if self.args.reg else loss_log
+        self._static_finish(adam, loss, always_step=True)
+        with torch.no_grad():
+            loss_val, acc_val = self._nll_acc(output.detach(), labels, self.idx_val, graph)
+        return {"loss_train": loss_log.detach(), "acc_train": acc_train, "loss_reg": reg_log.detach(),
+                "loss_val": loss_val, "acc_val": acc_val}
+
     def test(self, data, labels, epoch=0):
         for m in self.models:
             m.eval()

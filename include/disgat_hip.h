@@ -45,6 +45,8 @@
  *   part_z / part_den   [n_slots][H][F_in] / [n_slots][2][H] partial records of split rows
  *   drop_p, drop_seed   attention dropout (layers.py:394): edge k, head h is kept iff the top 32 bits
  *                       of splitmix64(seed + (k*H+h)*0x9E3779B97F4A7C15) >= p*2^32; p = 0 disables it
+ *   drop_seed_dev       NULL, or a device uint64 added to drop_seed when the kernel runs: a step captured in a HIP
+ *                       graph bakes drop_seed in, the graph advances this counter itself between replays
  *   sign_bits           att 3 only, optional (NULL = not recorded): uint32 [E | M][64].  Word l of a row belongs
  *                       to lane l = (head h = l / G, g = l % G), G = 64/H, QN = F_out / (4*G); its bit
  *                       8*k + QN-1-j is (P[row] + Q[col] > 0) at feature h*F_out + (j*G+g)*4 + k (k < 4,
@@ -91,7 +93,7 @@ int disgat_edge_fwd(int att, const int32_t* items, int n_items, const int32_t* c
                     const float* a,
                     float* Z, float* edge_e, float* den,
                     float* part_z, float* part_den,
-                    int sage_div, float drop_p, uint64_t drop_seed,
+                    int sage_div, float drop_p, uint64_t drop_seed, const uint64_t* drop_seed_dev,
                     uint32_t* sign_bits, const float* e_in,
                     uint16_t* Z_hi, uint16_t* Z_lo, const float* z_bound, disgat_stream_t stream);
 
@@ -112,6 +114,8 @@ int disgat_aux_score(int att, const int64_t* pair_rows, const int64_t* pair_cols
 
 /* Weighted squared-error partial sums of pred = sigmoid(sum_{h in [h_lo,h_hi)} aux[h][m])
  * against 0/1 labels: acc[0] += sum over positives, acc[1] += sum over zeros, acc[2] += #positives.
+ * A NEGATIVE label marks padding (a fixed-capacity list whose valid length lives on the device, as a step captured
+ * in a HIP graph needs): such an entry enters no sum and gets a zero gradient from disgat_pair_loss_bwd.
  * acc (3 doubles) must be zeroed by the caller; block_partials: scratch for DISGAT_PAIR_LOSS_MAX_BLOCKS x 3 doubles
  * (per-block sums, added in block order by a second tiny launch: the value is run-to-run deterministic). */
 #define DISGAT_PAIR_LOSS_MAX_BLOCKS 2048
@@ -131,7 +135,7 @@ int disgat_pair_loss_bwd(const float* aux, int64_t M, int H, int h_lo, int h_hi,
 int disgat_bwd_alpha(const int32_t* items, int n_items, const int32_t* col, int64_t E, int H, int F_in,
                      const float* x, int ldx, const float* gZ, const float* Z, const float* edge_e,
                      const float* den, const float* ge_in, float* ge_out, float* beta, int sage_div,
-                     float drop_p, uint64_t drop_seed, disgat_stream_t stream);
+                     float drop_p, uint64_t drop_seed, const uint64_t* drop_seed_dev, disgat_stream_t stream);
 
 /* Segment gradient of the att-3 score e = sum_f a_f lrelu(keyop[key] + otherop[other]).
  * items = {key, m_begin, m_end, slot} over a list sorted by key; other[m] = gathered node of list
@@ -273,6 +277,14 @@ int disgat_adam_multi(int count, float* const* params, const float* const* grads
                       float* const* exp_avg_sq, const int64_t* numel, const float* step_size,
                       const float* inv_sqrt_bc2, const float* weight_decay, double beta1, double beta2, float eps,
                       disgat_stream_t stream);
+
+/* The same step with the step counts on the DEVICE: steps[i] (int32, device memory) = t of tensor i, already advanced by
+ * the caller - inside a train_step captured in a HIP graph, by an op of the same graph; lr[i] (host, double) is the plain
+ * learning rate and the two bias corrections are formed in the kernel, in double like the host forms them above.  A
+ * replayed graph would otherwise repeat the corrections of the step it was captured at. */
+int disgat_adam_multi_dev(int count, float* const* params, const float* const* grads, float* const* exp_avg,
+                          float* const* exp_avg_sq, const int64_t* numel, const double* lr, const float* weight_decay,
+                          const int32_t* steps, double beta1, double beta2, float eps, disgat_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -178,7 +178,7 @@ def test_launchers_reject_bad_arguments(dev):
     with pytest.raises(RuntimeError, match="multiple"):
         ops.edge_forward(g, 3, 4, 16, 40, x, p, p, torch.randn(160, device=dev), False)
     with pytest.raises(RuntimeError, match="not in 1..3"):
-        _lib.call("disgat_edge_fwd", 7, 0, 0, 0, 0, 1, 4, 16, 64, 0, 16, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.0, 0, 0, 0, 0, 0, 0, 0)
+        _lib.call("disgat_edge_fwd", 7, 0, 0, 0, 0, 1, 4, 16, 64, 0, 16, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.0, 0, 0, 0, 0, 0, 0, 0, 0)
     with pytest.raises(RuntimeError, match="int64 device tensor"):
         ops.aux_forward(3, 4, 16, 64, torch.zeros(2, 5, dtype=torch.int32, device=dev), n, x, p, p, p[0], 0, 4)
     # an id outside the operand tables raises on the host instead of faulting on the device

@@ -22,8 +22,11 @@ WEIGHTS = [1.0, 0.5, 2.0]
 PTOL = 4e-4
 
 
-@pytest.mark.parametrize("gnn,att", [("AT", 3), ("SAGE", 1), ("GCN", 2), ("SAGE", 3)])
-def test_parameters_after_three_epochs_match_the_reference(golden_dir, dev, gnn, att):
+@pytest.mark.parametrize("gnn,att,captured", [("AT", 3, False), ("SAGE", 1, False), ("GCN", 2, False), ("SAGE", 3, False),
+                                              ("AT", 3, True), ("SAGE", 1, True), ("GCN", 2, True)])
+def test_parameters_after_three_epochs_match_the_reference(golden_dir, dev, gnn, att, captured):
+    """captured=True: the same twelve steps replayed from HIP graphs (Trainer.train_step_captured: rolled-back warm-up,
+    capture, replays from step 1 on), the golden lists behind the static samplers' interface."""
     import random
     from edgedisentangle_ssl_amd import pretrainer, utils
     from edgedisentangle_ssl_amd.trainer import ClsTrainer
@@ -64,12 +67,29 @@ def test_parameters_after_three_epochs_match_the_reference(golden_dir, dev, gnn,
     trs[1].sample_train = lambda: ([ho[1], he[1]], [ho[0], he[0]])
     data = (x, adj)
     logs, cls_logs = [], []
+    if captured:
+        from edgedisentangle_ssl_amd import sampling
+        from edgedisentangle_ssl_amd.graph import graph_of
+        data = (x, graph_of(adj))
+        fixed = [sampling.FixedList(p[0], p[1], n) for p in (sup, ho, he)]
+        trs[0]._static_sampler = lambda gt: fixed[0]
+        trs[1].graph, trs[1]._samplers = data[1], fixed[1:]
+        lab_dev = labels.to(dev)
     for ep in range(3):
+        if captured:        # the logs are the graph's static outputs: read (or clone) before the next replay
+            lg = utils.resolve_logs(ct.train_step_captured(data, lab_dev))
+            cls_logs.append([float(lg[k]) for k in ("loss_train", "acc_train", "loss_reg", "loss_val", "acc_val")])
+            logs.append(trs[0].train_step_captured(data)["loss_heads_sup"].clone())
+            logs.append(trs[1].train_step_captured(data)["loss_head_disen"].clone())
+            logs.append(trs[2].train_step_captured(data)["loss_head_diversity"].clone())
+            continue
         lg = utils.resolve_logs(ct.train_step(data, labels.to(dev), ep))          # main.py:313-352: fine-tuning step, then SSL
         cls_logs.append([float(lg[k]) for k in ("loss_train", "acc_train", "loss_reg", "loss_val", "acc_val")])
         logs.append(trs[0].train_step(data)["loss_heads_sup"])
         logs.append(trs[1].train_step(data)["loss_head_disen"])
         logs.append(trs[2].train_step(data)["loss_head_diversity"])
+    if captured:
+        assert all(tr.static_step().replays == 3 and tr.static_step().graph is not None for tr in [ct] + trs)
     np.testing.assert_allclose(np.asarray(cls_logs), g["cls_logs"], rtol=2e-4, atol=2e-5)
     lt = ct.test(data, labels.to(dev))
     # loss / accuracy / sklearn ROC-AUC and macro-F1 of the test split (trainer.py:296-318)

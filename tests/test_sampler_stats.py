@@ -17,7 +17,7 @@ import torch
 import inputs_common as ic
 
 
-def _stats(dev, golden_dir, draws=600):
+def _stats(dev, golden_dir, draws=600, static=False):
     from edgedisentangle_ssl_amd import sampling
     from edgedisentangle_ssl_amd.graph import CSRGraph
     idx, _vals, n = ic.tiny_graph()
@@ -28,8 +28,17 @@ def _stats(dev, golden_dir, draws=600):
     hgen = torch.Generator().manual_seed(12)
     p3 = 3.0 * npos / (n * n)
     ms, hit = [], torch.zeros(n * n, device=dev)
+    smp = sampling.StaticSampler(n, pos) if static else None
     for _ in range(draws):
-        pidx, lab = sampling.sample_pairs(n, pos, gen, host_generator=hgen)
+        if static:      # the fixed-capacity form captured steps use: valid prefix + padding (label -1, pair (n-1, n-1))
+            smp.draw_k(hgen)
+            pidx, lab = smp.sample(gen)
+            c = int(lab._disgat_count)
+            assert pidx.shape[1] == smp.capacity == lab.shape[0] and getattr(pidx, "_disgat_static", False)
+            assert torch.all(lab[c:] == -1) and torch.all(pidx[:, c:] == n - 1)
+            pidx, lab = pidx[:, :c], lab[:c]
+        else:
+            pidx, lab = sampling.sample_pairs(n, pos, gen, host_generator=hgen)
         flat = pidx[0] * n + pidx[1]
         assert torch.all(flat[1:] > flat[:-1])                       # mask.nonzero() order, no duplicates
         assert torch.equal(lab, torch.isin(flat, pos).float())
@@ -41,6 +50,8 @@ def _stats(dev, golden_dir, draws=600):
     # E[M] = N^2 p3 + third * (1 - p3);  Var[M] = (N^2 - third) p3 (1 - p3)   (entries outside the third are Bernoulli)
     mean = n * n * p3 + third * (1 - p3)
     var = (n * n - third) * p3 * (1 - p3)
+    if static:
+        assert int(smp.short) == 0 and smp.clamped == 0
     assert abs(ms.mean() - mean) < 4 * np.sqrt(var / draws), (ms.mean(), mean)
     assert 0.8 * var < ms.var() < 1.25 * var, (ms.var(), var)
     ref = np.load(os.path.join(golden_dir, "tiny_ref_sampler.npz"))
@@ -63,6 +74,15 @@ def _stats(dev, golden_dir, draws=600):
 
 def test_sampler_distribution_cpu(golden_dir):
     _stats(torch.device("cpu"), golden_dir)
+
+
+def test_static_sampler_distribution_cpu(golden_dir):
+    _stats(torch.device("cpu"), golden_dir, static=True)
+
+
+@pytest.mark.gpu
+def test_static_sampler_distribution_gpu(golden_dir):
+    _stats(torch.device("cuda:0"), golden_dir, static=True)
 
 
 @pytest.mark.gpu
