@@ -207,6 +207,7 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void seg_grad_att3_kernel(const Se
   for (int item = wave; item < A.n_items; item += n_waves) {   // persistent: ga stays in registers
     const int4 it = A.items[item];
     const int key = rfl(it.x), mb = rfl(it.y), me = rfl(it.z), slot = rfl(it.w);
+    if (key < 0) continue;          // padding item of a fixed-capacity item table (captured steps)
     f32x4 p_r[QN], gk[QN], qA[QN], qB[QN];
     {
       const float* pp = A.keyop + (size_t)key * A.ld_key + qoff;
@@ -318,6 +319,7 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void seg_grad_sign_kernel(const Si
   for (int item = wave; item < A.n_items; item += n_waves) {   // persistent: ga stays in registers
     const int4 it = A.items[item];
     const int key = rfl(it.x), mb = rfl(it.y), me = rfl(it.z), slot = rfl(it.w);
+    if (key < 0) continue;          // padding item of a fixed-capacity item table (captured steps)
     f32x4 up[QN];
 #pragma unroll
     for (int j = 0; j < QN; ++j) up[j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -382,6 +384,7 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void seg_grad_hx_row_kernel(const 
   if (item >= A.n_items) return;
   const int4 it = A.items[item];
   const int key = rfl(it.x), mb = rfl(it.y), me = rfl(it.z), slot = rfl(it.w);
+  if (key < 0) return;              // padding item of a fixed-capacity item table (captured steps)
   const int xoff = lane * 4;
   const int myh = lane & (H - 1);
   const bool hact = (myh >= A.h_lo) && (myh < A.h_hi);
@@ -436,6 +439,7 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void seg_grad_hx_col_kernel(const 
   if (item >= A.n_items) return;
   const int4 it = A.items[item];
   const int key = rfl(it.x), mb = rfl(it.y), me = rfl(it.z), slot = rfl(it.w);
+  if (key < 0) return;              // padding item of a fixed-capacity item table (captured steps)
   const int xoff = lane * 4;
   const int myh = lane & (H - 1);
   const bool hact = (myh >= A.h_lo) && (myh < A.h_hi);
@@ -488,6 +492,7 @@ __global__ __launch_bounds__(256) void seg_combine_kernel(const int32_t* __restr
                                                           int width, const float* __restrict__ part, int ld, float* __restrict__ gkey,
                                                           int accumulate) {
   const int key = split_keys[blockIdx.x];
+  if (key < 0) return;              // padding entry of a fixed-capacity split table
   const int s0 = split_ptr[blockIdx.x], s1 = split_ptr[blockIdx.x + 1];
   float* out = gkey + (size_t)key * ld;
   for (int c = threadIdx.x * 4; c < width; c += 256 * 4) {

@@ -810,6 +810,22 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_tn_kernel(const GemmTNArgs 
         P[(int64_t)(16 * i + 4 * (lane >> 4) + r) * T.N + 16 * j + (lane & 15)] = fmaf(acx[i][j][r], xw, acc[i][j][r] * inv);
 }
 
+// max over the block of a per-thread bit pattern (non-negative floats order like unsigned integers), then ONE atomicMax per
+// block - and only when the block's value can still raise *out.  One atomic per WAVE, as before, serialises at the L2: the
+// first few thousand waves of a launch all start against *out == 0 and queue up on the same address (an amax over 21 MB took
+// 70 us, 0.64 ms over 1 GB).  Call with all 256 threads.
+__device__ __forceinline__ void block_atomic_max(uint32_t m, uint32_t* __restrict__ out) {
+  __shared__ uint32_t wave_max[4];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+  if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3]));
+    if (m > __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out, m);
+  }
+}
+
 // Weight preparation for the f16x3 scheme in two small launches (the torch formulation took ~15): max |W| over an
 // arbitrarily strided [batch][K][N] weight, then hi / lo planes of (W^T * s) as [batch][2][N][K] fp16 and s itself.
 __global__ __launch_bounds__(256) void wamax_kernel(const float* __restrict__ W, int64_t sb, int64_t sk, int64_t sn, int K,
@@ -821,9 +837,7 @@ __global__ __launch_bounds__(256) void wamax_kernel(const float* __restrict__ W,
     const int64_t k = r / N, n = r - k * N;
     m = max(m, __float_as_uint(fabsf(W[b * sb + k * sk + n * sn])));
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
-  if ((threadIdx.x & 63) == 0 && m > __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out, m);   // most waves find a larger value already there: tens of atomics, not tens of thousands
+  block_atomic_max(m, out);
 }
 
 __global__ __launch_bounds__(256) void wsplit_kernel(const float* __restrict__ W, int64_t sb, int64_t sk, int64_t sn, int K,
@@ -882,9 +896,7 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ A, 
       upd(ld4(A + bz * a_bs + rm * lda + c));
     }
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
-  if ((threadIdx.x & 63) == 0 && m > __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out, m);   // most waves find a larger value already there: tens of atomics, not tens of thousands
+  block_atomic_max(m, out);
 }
 
 }  // namespace disgat
@@ -909,11 +921,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
     st4(gin + i * 4, r);
     m = max(max(m, __float_as_uint(fabsf(r.x))), max(__float_as_uint(fabsf(r.y)), max(__float_as_uint(fabsf(r.z)), __float_as_uint(fabsf(r.w)))));
   }
-  if (amax_out != nullptr) {          // max |gin| for the GEMMs that consume it (saves them a pass over gin)
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
-    if ((threadIdx.x & 63) == 0 && m > __hip_atomic_load(amax_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(amax_out, m);
-  }
+  if (amax_out != nullptr) block_atomic_max(m, amax_out);   // max |gin| for the GEMMs that consume it (saves them a pass over gin)
 }
 }  // namespace disgat
 
@@ -929,7 +937,8 @@ extern "C" int disgat_act_bwd(const float* g, const float* out, float* gin, int6
   DISGAT_REQUIRE(act == 1 || act == 2, "act_bwd: act=%d (1 = ELU, 2 = leaky ReLU)", act);
   DISGAT_REQUIRE(aligned16(g) && aligned16(out) && aligned16(gin), "act_bwd: buffers must be 16-byte aligned");
   const int64_t n4 = n / 4;
-  const int grid = (int)((n4 + 255) / 256 < 65536 ? (n4 + 255) / 256 : 65536);
+  const int64_t want = n4 / (256 * 4) + 1;             // >= 4 float4 per thread, at most 4096 blocks
+  const int grid = (int)(want < 4096 ? want : 4096);
   hipLaunchKernelGGL(act_bwd_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), g, out, gin, n4,
                      act, slope, reinterpret_cast<uint32_t*>(amax_out));
   return check_launch("act_bwd_kernel");
@@ -1003,7 +1012,8 @@ extern "C" int disgat_amax(const float* A, int64_t lda, int64_t a_batch_stride, 
   DISGAT_REQUIRE(K % 4 == 0 && lda % 4 == 0 && a_batch_stride % 4 == 0 && aligned16(A), "amax: K, lda and the batch stride must be multiples of 4, A 16-byte aligned");
   const int64_t rows = (int64_t)M * batch;
   const int64_t work = rows * (K / 4);
-  const int grid = (int)(work / 256 + 1 < 8192 ? work / 256 + 1 : 8192);
+  const int64_t want = work / (256 * 8) + 1;           // >= 8 float4 per thread, at most 2048 blocks (8 per CU)
+  const int grid = (int)(want < 2048 ? want : 2048);
   hipLaunchKernelGGL(amax_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), A, lda, a_batch_stride,
                      rows, M, K / 4, reinterpret_cast<uint32_t*>(out));
   return check_launch("amax_kernel");

@@ -14,6 +14,25 @@ from .graph import CSRGraph
 # same-box T_fwd at C4 with 64 / 128 / 256 / 512 / 1024 / 4096: 96.7 / 95.4 / 95.1 / 94.9 and 102.2 / 101.6 / 101.5 / 101.9 ms
 # on a slower box - the hub rows' slices start first, so coarser slices cost no tail and save partial records).
 CHUNK = {1: 256, 2: 256, 3: 512, 4: 512}
+_DEFAULT_CHUNK = dict(CHUNK)
+# Small graphs (Cora, chameleon: 1e4-1e5 edges) have fewer rows than the chip has wave slots and a hub row of a few hundred
+# edges is then the whole launch's critical path: below SMALL_ITEMS default-sized items the slices shrink until about that
+# many exist, but not below 4 H edges (a slice's partial record is H*F_in floats: keep it well under what the slice gathers).
+SMALL_ITEMS = 8192
+
+
+def chunk_small(att, count, H):
+    """Entries per work item for a list of `count` entries: CHUNK[att] (always, when a caller overrode it), smaller for
+    small lists."""
+    c = CHUNK[att]
+    if c != _DEFAULT_CHUNK.get(att) or count >= SMALL_ITEMS * c:
+        return c
+    small = max(16, 4 * int(H), 1 << max(0, (int(count) // SMALL_ITEMS).bit_length() - 1))
+    return min(c, small)
+
+
+def chunk_for(att, graph, H):
+    return chunk_small(att, graph.nnz, H)
 
 
 # bench.py sets PROFILE to a list: every launch is then bracketed by HIP events recorded on the
@@ -106,7 +125,7 @@ def edge_forward(graph: CSRGraph, att, H, F_in, F_out, x, rowop, colop, a, sage_
         _row_major(t, nm)
     n, e = graph.n, graph.nnz
     dev = x.device
-    wi = graph.work_items(CHUNK[att])
+    wi = graph.work_items(chunk_for(att, graph, H))
     z = zh = zl = None
     if z_bound is None:
         z = torch.empty((n, H, F_in), dtype=torch.float32, device=dev)

@@ -89,7 +89,7 @@ def edge_backward(ctx, gz, ge, want_ge=False):
     n, e = graph.n, graph.nnz
     if e == 0:                      # no edges: Z == 0 and no score exists, every gradient is zero
         return None, None, None, None, None, None
-    chunk = ops.CHUNK[att]
+    chunk = ops.chunk_for(att, graph, H)
     wi = graph.work_items(chunk)
     gz = torch.zeros_like(z) if gz is None else gz.contiguous()
     ge = None if ge is None else ge.contiguous()
@@ -157,7 +157,7 @@ def _segments_of(pairs, side, n_keys, chunk):
     if hit is not None:
         return hit[1]
     if getattr(pairs, "_disgat_static", False):
-        res = _segments_static(pairs[side], n_keys, side == 0)
+        res = _segments_static(pairs[side], n_keys, side == 0, chunk)
     else:
         res = _segments(pairs[side], n_keys, chunk)
     if len(_SEG_CACHE) >= 8:
@@ -179,26 +179,59 @@ def _segments(keys, n_keys, chunk):
     return build_items(ptr, chunk), perm, perm32
 
 
-def _segments_static(keys, n_keys, is_sorted):
+def _segments_static(keys, n_keys, is_sorted, chunk):
     """_segments() for the fixed-capacity lists of captured steps (sampling.StaticSampler): no size is read back and every
-    shape is fixed - one work item per key whatever its length (no slices, so no partial records; on the small graphs this
-    path serves a key's segment is a few hundred entries), items in key order."""
+    shape is fixed.  Keys longer than `chunk` entries are cut into near-equal slices exactly as build_items() cuts them,
+    but the item table has a fixed CAPACITY - n_keys + C // chunk bounds sum_k max(1, ceil(deg_k / chunk)) - and the
+    entries past the real count are padding (key -1: the kernels skip them), likewise the split-key table
+    (at most C // chunk keys are longer than chunk).  Items stay in key order."""
     from .graph import WorkItems
     dev = keys.device
+    c_len = int(keys.numel())
     if is_sorted:
         perm = perm32 = None
     else:
         perm = torch.sort(keys, stable=True).indices
         keys = keys[perm]
         perm32 = perm.to(torch.int32)
-    ptr = torch.searchsorted(keys, torch.arange(n_keys + 1, device=dev, dtype=keys.dtype)).to(torch.int32)
+    ptr = torch.searchsorted(keys, torch.arange(n_keys + 1, device=dev, dtype=keys.dtype))
     wi = WorkItems()
-    wi.items = torch.stack([torch.arange(n_keys, device=dev, dtype=torch.int32), ptr[:-1], ptr[1:],
-                            torch.full((n_keys,), -1, dtype=torch.int32, device=dev)], 1).contiguous()
-    wi.n_items = int(n_keys)
-    wi.n_split = wi.n_slots = 0
-    wi.split_rows = wi.split_ptr = torch.zeros(1, dtype=torch.int32, device=dev)
-    wi.chunk = None
+    wi.chunk = chunk
+    if not DETERMINISTIC or chunk >= c_len:          # no slices: one item per key
+        p32 = ptr.to(torch.int32)
+        wi.items = torch.stack([torch.arange(n_keys, device=dev, dtype=torch.int32), p32[:-1], p32[1:],
+                                torch.full((n_keys,), -1, dtype=torch.int32, device=dev)], 1).contiguous()
+        wi.n_items = int(n_keys)
+        wi.n_split = wi.n_slots = 0
+        wi.split_rows = wi.split_ptr = torch.zeros(1, dtype=torch.int32, device=dev)
+        return wi, perm, perm32
+    deg = ptr[1:] - ptr[:-1]
+    nchunk = torch.clamp((deg + chunk - 1) // chunk, min=1)
+    cum = torch.cumsum(nchunk, 0)
+    cap = n_keys + c_len // chunk
+    i = torch.arange(cap, device=dev, dtype=torch.int64)
+    valid = i < cum[-1]
+    key = torch.searchsorted(cum, i, right=True).clamp_(max=n_keys - 1)
+    nck, dk = nchunk[key], deg[key]
+    j = i - (cum[key] - nck)
+    size, rem = dk // nck, dk % nck
+    begin = ptr[:-1][key] + j * size + torch.minimum(j, rem)
+    end = begin + size + (j < rem).to(torch.int64)
+    split_item = valid & (nck > 1)
+    slot = torch.where(split_item, torch.cumsum(split_item.to(torch.int64), 0) - 1, torch.full_like(i, -1))
+    wi.items = torch.stack([torch.where(valid, key, torch.full_like(key, -1)), begin, end, slot], 1).to(torch.int32).contiguous()
+    wi.n_items = int(cap)
+    # split-key table: key ids in key order, -1 padded; split_ptr = exclusive prefix of the split keys' slice counts
+    n_split_cap = max(1, c_len // chunk)
+    is_split = nchunk > 1
+    rank = torch.cumsum(is_split.to(torch.int64), 0) - 1
+    where = torch.where(is_split, rank, torch.full_like(rank, n_split_cap))
+    rows = torch.full((n_split_cap + 1,), -1, dtype=torch.int64, device=dev).scatter_(0, where, torch.arange(n_keys, device=dev))
+    cnt = torch.zeros(n_split_cap + 2, dtype=torch.int64, device=dev).scatter_(0, where + 1, nchunk)   # last entry: the unsplit keys' dump
+    wi.split_rows = rows[:n_split_cap].to(torch.int32).contiguous()
+    wi.split_ptr = torch.cumsum(cnt[: n_split_cap + 1], 0).to(torch.int32).contiguous()
+    wi.n_split = int(n_split_cap)
+    wi.n_slots = int(2 * (c_len // chunk) + 2)        # sum over keys longer than chunk of ceil(deg / chunk) <= 2 C / chunk
     return wi, perm, perm32
 
 
@@ -221,7 +254,7 @@ def aux_backward(ctx, gout):
             g_col = torch.zeros_like(colop)
             g_col[:, lo:hi] = torch.zeros((colop.shape[0], hi - lo), dtype=torch.float32, device=dev).index_add_(0, cols, gsub)
         return g_x, g_row, g_col, g_a, None, None
-    chunk = ops.CHUNK[att]
+    chunk = ops.chunk_small(att, int(pairs.shape[1]), H)
     n_rows = rowop.shape[0]
     n_cols = colop.shape[0] if att in (3, 4) else x.shape[0]
     sign = getattr(ctx, "sign", None)
@@ -274,7 +307,7 @@ def layer_backward_remat(ctx, gz, ge, gaux):
     need_x, need_row, need_col, need_a = ctx.needs_input_grad[:4]
     dev = x.device
     n, e = graph.n, graph.nnz
-    chunk = ops.CHUNK[att]
+    chunk = ops.chunk_for(att, graph, H)
     n_rows, n_cols = int(rec_p[0].shape[0]), int(rec_q[0].shape[0])
     have_edge = (gz is not None or ge is not None) and e > 0
     ge_tot = beta = t = twi = None
@@ -305,7 +338,7 @@ def layer_backward_remat(ctx, gz, ge, gaux):
             g_row, ga = _seg_sign(wi, None, ge_tot, 0, H, H, f_out, ctx.sign, rowop, a, n, need_a)
             add_ga(ga)
         for pairs, (lo, hi), sg, gout in live:
-            wl, _perm, perm32 = _segments_of(pairs, 0, n_rows, chunk)
+            wl, _perm, perm32 = _segments_of(pairs, 0, n_rows, ops.chunk_small(att, int(pairs.shape[1]), H))
             g_row, ga = _seg_sign(wl, perm32, gout, lo, hi, H, f_out, sg, rowop, a, n_rows, need_a, into=g_row)
             add_ga(ga)
         del rowop
@@ -317,7 +350,7 @@ def layer_backward_remat(ctx, gz, ge, gaux):
             add_ga(ga)
         ctx.sign = None
         for li, (pairs, (lo, hi), sg, gout) in enumerate(live):
-            wl, _perm, perm32 = _segments_of(pairs, 1, n_cols, chunk)
+            wl, _perm, perm32 = _segments_of(pairs, 1, n_cols, ops.chunk_small(att, int(pairs.shape[1]), H))
             g_col, ga = _seg_sign(wl, perm32, gout, lo, hi, H, f_out, sg, colop, a, n_cols, need_a, into=g_col)
             add_ga(ga)
             live[li] = None
@@ -344,13 +377,13 @@ def layer_backward(ctx, gz, ge, gaux):
                                needs_input_grad=ctx.needs_input_grad, sign=ctx.sign)
         g_x, g_row, g_col, g_a, _, _ge = edge_backward(ectx, gz, ge)
     ctx.sign = None                    # 256 B per edge: the record is dead once both segment passes have read it
-    chunk = ops.CHUNK[att]
     n_rows, n_cols = rowop.shape[0], colop.shape[0]
     for li, (pairs, (lo, hi), gout) in enumerate(zip(lists, ranges, gaux)):
         sign, ctx.aux_signs[li] = ctx.aux_signs[li], None          # 256 B per pair (17 GB for a 66M-pair list): freed list by list
         if gout is None or sign is None:
             continue
         gout = gout.contiguous()
+        chunk = ops.chunk_small(att, int(pairs.shape[1]), H)
         if need_row or need_a:
             wi, _perm, perm32 = _segments_of(pairs, 0, n_rows, chunk)
             g_row, ga = _seg_sign(wi, perm32, gout, lo, hi, H, f_out, sign, rowop, a, n_rows, need_a, into=g_row)

@@ -142,7 +142,9 @@ int disgat_bwd_alpha(const int32_t* items, int n_items, const int32_t* col, int6
  * position m; perm[m] (or NULL = identity) = column of g holding that position's upstream grad.
  * gkey[key] = sum_m g*a*lrelu'(z) (plain store, or atomic add into host-zeroed rows when slot >= 0);
  * ga_part (or NULL): [n_waves][H*F_out] per-wave partial sums of g*lrelu(z) (sum them on the host).
- * n_waves: multiple of 4; the launch is persistent (grid-stride over items). */
+ * n_waves: multiple of 4; the launch is persistent (grid-stride over items).
+ * In all segment launchers an item with key < 0 is padding and does nothing, and so does a negative entry of
+ * disgat_seg_combine's split_keys: item tables of FIXED size for steps captured in a HIP graph. */
 int disgat_seg_grad_att3(const int32_t* items, int n_items, const int32_t* other, const int32_t* perm,
                          const float* g, int64_t g_stride, int h_lo, int h_hi, int H, int F_out,
                          const float* keyop, int ld_key, const float* otherop, int ld_other, const float* a,
