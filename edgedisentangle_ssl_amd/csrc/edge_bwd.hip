@@ -176,7 +176,7 @@ struct SegArgs {
   int ld_key;
   const float* otherop;
   int ld_other;
-  const float* a;
+  const float* a;        // [H*FQ], or null: gkey receives u itself instead of a (.) u
   float* gkey;
   int ld_gkey;
   float* ga_part;        // [n_waves][H*FQ] or null
@@ -289,7 +289,7 @@ struct SignArgs {
   const uint32_t* sign;  // [M][64] sign words (disgat_common.h)
   const float* keyop;    // P (row pass) or Q (column pass); read only when ga_part != null
   int ld_key;
-  const float* a;
+  const float* a;        // [H*FQ], or null: gkey receives u itself instead of a (.) u
   float* gkey;
   int ld_gkey;
   float* ga_part;        // [n_waves][H*FQ] or null
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void seg_grad_sign_kernel(const Si
       const f32x4 u = 0.99f * up[j] + base;
       if (want_ga) ga[j] += ld4(pp + j * G * 4) * u;
       if (to_part || !A.accumulate || active)
-        out4(op + j * G * 4, ld4(A.a + qoff + j * G * 4) * u, slot >= 0 && !to_part, A.accumulate != 0 && !to_part);
+        out4(op + j * G * 4, A.a ? ld4(A.a + qoff + j * G * 4) * u : u, slot >= 0 && !to_part, A.accumulate != 0 && !to_part);
     }
   }
   if (want_ga) {
@@ -605,11 +605,11 @@ extern "C" int disgat_seg_grad_sign(const int32_t* items, int n_items, const int
   const int hl = ilog2_exact(H);
   DISGAT_REQUIRE(hl >= 1 && hl <= 4, "seg_grad_sign: H=%d must be a power of two in [2,16]", H);
   DISGAT_REQUIRE(h_lo >= 0 && h_hi <= H && h_lo < h_hi, "seg_grad_sign: bad head range [%d,%d)", h_lo, h_hi);
-  DISGAT_REQUIRE(items && g && sign_bits && a && gkey && n_items > 0, "seg_grad_sign: null pointer");
+  DISGAT_REQUIRE(items && g && sign_bits && gkey && n_items > 0, "seg_grad_sign: null pointer");
   DISGAT_REQUIRE(ga_part == nullptr || keyop != nullptr, "seg_grad_sign: ga_part needs keyop");
   const int g4 = (64 >> hl) * 4;
   DISGAT_REQUIRE(F_out > 0 && F_out % g4 == 0, "seg_grad_sign: bad F_out=%d", F_out);
-  DISGAT_REQUIRE(ld_gkey % 4 == 0 && ld_key % 4 == 0 && aligned16(a) && aligned16(gkey) && (keyop == nullptr || aligned16(keyop)),
+  DISGAT_REQUIRE(ld_gkey % 4 == 0 && ld_key % 4 == 0 && (a == nullptr || aligned16(a)) && aligned16(gkey) && (keyop == nullptr || aligned16(keyop)),
                  "seg_grad_sign: strides must be multiples of 4 floats and bases 16-byte aligned");
   DISGAT_REQUIRE(n_waves > 0 && n_waves % DISGAT_WAVES_PER_BLOCK == 0, "seg_grad_sign: n_waves must be a positive multiple of %d", DISGAT_WAVES_PER_BLOCK);
   const int qn = F_out / g4;

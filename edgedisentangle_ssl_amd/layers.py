@@ -247,10 +247,13 @@ def _pack_score_operands(layers, x, x_all, att, H, Hp, f_in, f_out, fp, am=None,
 
 
 # The att-3 score operands P = x W_top, Q = x_all W_bot ([N, H*F_out] each: 8 GB apiece at C4) are outputs of one GEMM
-# and inputs of one fused pass; the pass's backward needs them again (grad a = sum P (.) u + sum Q (.) v).  Saved, they are
-# the largest thing a training step holds between forward and backward: 2 layers x 2 x 8 GB of a 119 GiB peak.  With
-# REMAT_SCORE_OPERANDS the pass saves the RECIPE instead (input, packed weight - both alive anyway) and the backward
-# recomputes the operand: 4 GEMMs of ~3.3 ms per training step for -32 GB.  DISGAT_REMAT=0 keeps them.
+# and inputs of one fused pass.  Saved for the backward they were the largest thing a training step held (2 layers x 2 x
+# 8 GB of a 119 GiB peak), and all the backward wanted from them was grad a = sum P (.) u + sum Q (.) v.  With
+# REMAT_SCORE_OPERANDS (default) the fused pass owns the two GEMMs instead (ops.LayerPass + ops_bwd.layer_backward_u): the
+# segment passes return u without the a-scale, G = x^T u is the weight-gradient GEMM that runs anyway, and
+# grad W = G (.) a, grad a = sum_rows W (.) G, grad x = u (W (.) a)^T - no operand is saved, rebuilt or read.  The few passes
+# that stay on ops.EdgePass (feature / column slices) rebuild their operands through saved-tensor hooks.  DISGAT_REMAT=0
+# keeps the operands (ops_bwd.layer_backward).
 REMAT_SCORE_OPERANDS = os.environ.get("DISGAT_REMAT", "1") != "0"
 
 
@@ -425,7 +428,9 @@ def disga_heads(layers, x, adj, aux_indices=None, head_ranges=None, aux_only=Fal
     # differentiable att-3 layer with aux lists, one head group, no column slices (the training configuration): the edge
     # pass and all aux lists form ONE autograd node, so P / Q / a get one gradient each (ops.LayerPass)
     merged_aux = None
-    merge = rec and not aux_only and aux_indices and n_groups == 1 and f_in_p <= tile and len(f_slices) == 1
+    recipes = (getattr(rowop, "_disgat_remat", None), getattr(colop, "_disgat_remat", None))
+    own = bool(REMAT_SCORE_OPERANDS and att == 3 and None not in recipes)      # the pass can own the operands' GEMMs (ops.LayerPass)
+    merge = rec and not aux_only and (aux_indices or own) and n_groups == 1 and f_in_p <= tile and len(f_slices) == 1
     heads = e_list = None
     concat = all(l.concat for l in layers)
     # plane-operand chain (csrc/gemm_planes.hip): edge pass -> Z planes -> projection -> head planes -> fuser.  One head
@@ -437,13 +442,19 @@ def disga_heads(layers, x, adj, aux_indices=None, head_ranges=None, aux_only=Fal
         for gi in range(n_groups):
             r, c, av, d = group_ops(gi)
             if merge:
+                lists = aux_indices or []
                 ranges = tuple((0, H) if head_ranges is None or head_ranges[li] is None else tuple(head_ranges[li])
-                               for li in range(len(aux_indices)))
+                               for li in range(len(lists)))
                 cfg = (graph, att, Hk, f_in_p, fp, gnn == "SAGE", d, ranges)
-                recipes = (getattr(rowop, "_disgat_remat", None), getattr(colop, "_disgat_remat", None))
-                if REMAT_SCORE_OPERANDS and att == 3 and None not in recipes:
-                    cfg = cfg + (recipes,)          # the pass keeps the recipes, not P / Q (ops_bwd.layer_backward_remat)
-                z, edge_e, _den, *merged_aux = ops.LayerPass.apply(xg, r, c, av, cfg, *aux_indices)
+                if own:
+                    # the pass owns P = x W_top and Q = x_all W_bot: their values go in detached, nothing of them is kept
+                    # for the backward, which returns gradients for the GEMMs' inputs instead (ops_bwd.layer_backward_u)
+                    (x_p, w_top, am_p, _s1), (x_q, w_bot, am_q, _s2) = recipes
+                    z, edge_e, _den, *maux = ops.LayerPass.apply(xg, r.detach(), c.detach(), av, cfg + ((am_p, am_q),), *lists,
+                                                                 x_p, w_top, x_q, w_bot)
+                else:
+                    z, edge_e, _den, *maux = ops.LayerPass.apply(xg, r, c, av, cfg, *lists)
+                merged_aux = maux if aux_indices else None
             elif use_pl:
                 # no-graph forward: the aggregate leaves the edge pass as the two fp16 planes the projection GEMM consumes
                 z, edge_e, _den = ops.edge_forward(graph, att, Hk, f_in_p, fp, xg, r, c, av, gnn == "SAGE", d, need_den=False,

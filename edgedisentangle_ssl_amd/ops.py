@@ -264,12 +264,17 @@ class LayerPass(torch.autograd.Function):
     """Edge pass + every aux list of one att-3 layer as ONE autograd node (differentiable forwards with a sign
     record): the score operands P, Q and `a` then receive one gradient each, accumulated list after list inside the
     backward kernels, instead of one full [N, H*F_out] tensor per consumer summed by autograd.
-    cfg = (graph, att, H, F_in, F_out, sage, drop, ranges) with ranges[i] = (h_lo, h_hi) of aux list i."""
+    cfg = (graph, att, H, F_in, F_out, sage, drop, ranges) with ranges[i] = (h_lo, h_hi) of aux list i; the tensors after
+    cfg are the aux lists.  With a ninth cfg entry (am_p, am_q) the node also OWNS the GEMMs behind P and Q: four more
+    tensors follow the lists - x_p, W_top, x_q, W_bot with rowop = x_p W_top, colop = x_q W_bot - rowop / colop are taken
+    as plain values (detached), nothing of them is saved, and the backward hands gradients to those four instead
+    (ops_bwd.layer_backward_u: no operand table is read or rebuilt)."""
 
     @staticmethod
-    def forward(ctx, x, rowop, colop, a, cfg, *lists):
+    def forward(ctx, x, rowop, colop, a, cfg, *rest):
         graph, att, H, F_in, F_out, sage, drop, ranges = cfg[:8]
-        ctx.remat = cfg[8] if len(cfg) > 8 else None      # (recipe of P, recipe of Q): rebuild them in the backward
+        ctx.u_am = cfg[8] if len(cfg) > 8 else None
+        lists = rest[:len(ranges)]
         ctx.sign = sign_record(att, H, F_out, graph.nnz, x.device) if graph.nnz else None
         z, edge_e, den = edge_forward(graph, att, H, F_in, F_out, x, rowop, colop, a, sage, drop, sign=ctx.sign)
         outs, ctx.aux_signs = [], []
@@ -279,8 +284,8 @@ class LayerPass(torch.autograd.Function):
             outs.append(aux_forward(att, H, F_in, F_out, pairs, graph.n, None, rowop, colop, a, lo, hi, sign=sg))
             ctx.aux_signs.append(sg)
         ctx.cfg = cfg[:8]
-        if ctx.remat is not None:
-            ctx.save_for_backward(x, a, z, edge_e, den, *lists)
+        if ctx.u_am is not None:
+            ctx.save_for_backward(x, a, z, edge_e, den, *lists, *rest[len(ranges):])
         else:
             ctx.save_for_backward(x, rowop, colop, a, z, edge_e, den, *lists)
         ctx.mark_non_differentiable(den)
@@ -290,6 +295,6 @@ class LayerPass(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gz, ge, _gden, *gaux):
         from . import ops_bwd
-        if ctx.remat is not None:
-            return ops_bwd.layer_backward_remat(ctx, gz, ge, gaux)
+        if ctx.u_am is not None:
+            return ops_bwd.layer_backward_u(ctx, gz, ge, gaux)
         return ops_bwd.layer_backward(ctx, gz, ge, gaux)

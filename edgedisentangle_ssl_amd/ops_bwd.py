@@ -65,7 +65,7 @@ def _seg_sign(wi, perm, g, lo, hi, H, f_out, sign, keyop, a, n_keys, want_ga, in
     ga_part = torch.empty((n_waves, H * f_out), dtype=torch.float32, device=dev) if want_ga else None
     part = _part(wi, gkey)
     _lib.call("disgat_seg_grad_sign", wi.items.data_ptr(), wi.n_items, ops._ptr(perm), g.data_ptr(), g.stride(0), lo, hi,
-              H, f_out, sign.data_ptr(), keyop.data_ptr(), keyop.stride(0), a.data_ptr(), gkey.data_ptr(), gkey.stride(0),
+              H, f_out, sign.data_ptr(), ops._ptr(keyop), 0 if keyop is None else keyop.stride(0), ops._ptr(a), gkey.data_ptr(), gkey.stride(0),
               ops._ptr(ga_part), n_waves, int(into is not None), ops._ptr(part), ops._stream())
     _combine(wi, part, gkey, H * f_out, into is not None)
     return gkey, (ga_part.sum(0) if want_ga else None)
@@ -288,27 +288,26 @@ def aux_backward(ctx, gout):
     return g_x, g_row, g_col, g_a, None, None
 
 
-def _recompute(recipe):
-    """Score operand from its recipe (input, packed weight, amax, weight planes): the forward's own GEMM again."""
+def layer_backward_u(ctx, gz, ge, gaux):
+    """layer_backward for a pass that owns the GEMMs of its score operands (ops.LayerPass with cfg[8]; att 3 with sign
+    records): P = x_p W_top and Q = x_q W_bot are neither saved nor rebuilt.  The segment passes return u = sum g lrelu'
+    per key WITHOUT the a-scale (disgat_seg_grad_sign, a == NULL), and with G = x^T u - the weight-gradient GEMM that
+    runs anyway -   grad W = G (.) a,   grad a = sum_rows W (.) G  (= sum_key (x W)[key] (.) u[key]),   grad x = u (W (.) a)^T.
+    No pass reads an operand table; the row side is finished (and its 8 GB u freed) before the column side starts; the
+    sign records go list by list during the column phase."""
     from . import ops_gemm
-    a, w, am, ws = recipe
-    with torch.no_grad():
-        return ops_gemm._forward(a.detach(), w.detach(), None, None, ops_gemm.ACT_NONE, 0.0, am, ws)
-
-
-def layer_backward_remat(ctx, gz, ge, gaux):
-    """layer_backward for a pass that saved the RECIPES of P and Q instead of the operands (ops.LayerPass with
-    cfg[8]): att 3 with sign records only.  The row side of the edge list and of every aux list runs first on a
-    recomputed P, which is dropped before Q is rebuilt for the column sides - one 8 GB operand alive at a time instead of
-    two saved ones; the sign records go list by list during the column phase."""
-    x, a, z, edge_e, den, *lists = ctx.saved_tensors
     graph, att, H, f_in, f_out, sage, drop, ranges = ctx.cfg
-    rec_p, rec_q = ctx.remat
-    need_x, need_row, need_col, need_a = ctx.needs_input_grad[:4]
+    n_lists = len(ranges)
+    x, a, z, edge_e, den, *rest = ctx.saved_tensors
+    lists, (x_p, w_top, x_q, w_bot) = rest[:n_lists], rest[n_lists:]
+    am_p, am_q = ctx.u_am
+    need = ctx.needs_input_grad
+    need_x, need_a = need[0], need[3]
+    need_xp, need_wt, need_xq, need_wb = need[5 + n_lists: 9 + n_lists]
     dev = x.device
     n, e = graph.n, graph.nnz
     chunk = ops.chunk_for(att, graph, H)
-    n_rows, n_cols = int(rec_p[0].shape[0]), int(rec_q[0].shape[0])
+    n_rows, n_cols = int(x_p.shape[0]), int(x_q.shape[0])
     have_edge = (gz is not None or ge is not None) and e > 0
     ge_tot = beta = t = twi = None
     if have_edge:
@@ -322,46 +321,56 @@ def layer_backward_remat(ctx, gz, ge, gaux):
                   beta.data_ptr(), int(bool(sage)), float(drop[0]), int(drop[1]), ops._ptr(drop[2] if len(drop) > 2 else None), ops._stream())
         t = graph.transpose()
         twi = t.work_items(chunk)
-    g_x = g_row = g_col = g_a = None
-
-    def add_ga(ga):
-        nonlocal g_a
-        if need_a and ga is not None:
-            g_a = ga if g_a is None else g_a + ga
-
     live = [(pairs, rng, sg, go.contiguous()) for pairs, rng, sg, go in zip(lists, ranges, ctx.aux_signs, gaux)
             if go is not None and sg is not None]
-    # ---- row side: P
-    if need_row or need_a:
-        rowop = _recompute(rec_p)
+    g_a = None
+
+    def dense_side(x_in, w, u, am, need_in, need_w):
+        """(grad x_in, grad w, this side's share of grad a) from u [rows, H*F_out]."""
+        nonlocal g_a
+        if u is None:
+            return None, None
+        with torch.no_grad():
+            g_in, G = ops_gemm.linear_backward(x_in.detach(), (w.detach() * a.detach()) if need_in else w.detach(), u, am,
+                                               need_in, need_w or need_a)
+            g_w = None
+            if G is not None:
+                if need_a:
+                    ga = (w.detach() * G).sum(0)
+                    g_a = ga if g_a is None else g_a + ga
+                if need_w:
+                    g_w = G.mul_(a.detach())
+        return g_in, g_w
+
+    # ---- row side
+    u = None
+    if need_xp or need_wt or need_a:
         if have_edge:
-            g_row, ga = _seg_sign(wi, None, ge_tot, 0, H, H, f_out, ctx.sign, rowop, a, n, need_a)
-            add_ga(ga)
+            u, _ = _seg_sign(wi, None, ge_tot, 0, H, H, f_out, ctx.sign, None, None, n, False)
         for pairs, (lo, hi), sg, gout in live:
             wl, _perm, perm32 = _segments_of(pairs, 0, n_rows, ops.chunk_small(att, int(pairs.shape[1]), H))
-            g_row, ga = _seg_sign(wl, perm32, gout, lo, hi, H, f_out, sg, rowop, a, n_rows, need_a, into=g_row)
-            add_ga(ga)
-        del rowop
-    # ---- column side: Q; every record is dead after its column pass
-    if need_col or need_a:
-        colop = _recompute(rec_q)
+            u, _ = _seg_sign(wl, perm32, gout, lo, hi, H, f_out, sg, None, None, n_rows, False, into=u)
+    g_xp, g_wt = dense_side(x_p, w_top, u, am_p, need_xp, need_wt)
+    u = None
+    # ---- column side; every record is dead after its column pass
+    if need_xq or need_wb or need_a:
         if have_edge:
-            g_col, ga = _seg_sign(twi, t.eid, ge_tot, 0, H, H, f_out, ctx.sign, colop, a, n_cols, need_a)
-            add_ga(ga)
+            u, _ = _seg_sign(twi, t.eid, ge_tot, 0, H, H, f_out, ctx.sign, None, None, n_cols, False)
         ctx.sign = None
         for li, (pairs, (lo, hi), sg, gout) in enumerate(live):
             wl, _perm, perm32 = _segments_of(pairs, 1, n_cols, ops.chunk_small(att, int(pairs.shape[1]), H))
-            g_col, ga = _seg_sign(wl, perm32, gout, lo, hi, H, f_out, sg, colop, a, n_cols, need_a, into=g_col)
-            add_ga(ga)
+            u, _ = _seg_sign(wl, perm32, gout, lo, hi, H, f_out, sg, None, None, n_cols, False, into=u)
             live[li] = None
             sg = None
-        del colop
     ctx.sign = None
     ctx.aux_signs = [None] * len(ctx.aux_signs)
+    g_xq, g_wb = dense_side(x_q, w_bot, u, am_q, need_xq, need_wb)
+    u = None
+    g_x = None
     if have_edge and need_x:
         g_x = _keybuf(tuple(x.shape), dev, twi, x.stride(0) != f_in)
         _seg_hx(1, twi, t.col, t.eid, beta, 0, H, H, f_in, gz.view(n, H * f_in), g_x, False)
-    return (g_x, g_row if need_row else None, g_col if need_col else None, g_a if need_a else None, None) + (None,) * len(lists)
+    return (g_x, None, None, g_a if need_a else None, None) + (None,) * n_lists + (g_xp, g_wt, g_xq, g_wb)
 
 
 def layer_backward(ctx, gz, ge, gaux):

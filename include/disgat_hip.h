@@ -157,7 +157,10 @@ int disgat_seg_grad_att3(const int32_t* items, int n_items, const int32_t* other
  * The a-gradient of a list is the sum of the row-side pass (keyop = P) and the column-side pass (keyop = Q),
  * because lrelu(z) = lrelu'(z) * (P + Q).  Reads 64 words + H floats per list position.
  * accumulate = 1 adds into gkey instead (several lists scoring against the same operands share one gradient buffer;
- * columns of heads outside [h_lo, h_hi) are then left untouched). */
+ * columns of heads outside [h_lo, h_hi) are then left untouched).
+ * a == NULL: gkey receives u itself.  With keyop = x W the operand's producer then needs no operand row at all:
+ * G = x^T u is the weight-gradient GEMM that runs anyway, grad W = G (.) a (per column), grad a = sum_rows W (.) G,
+ * grad x = u (W (.) a)^T. */
 int disgat_seg_grad_sign(const int32_t* items, int n_items, const int32_t* perm, const float* g,
                          int64_t g_stride, int h_lo, int h_hi, int H, int F_out, const uint32_t* sign_bits,
                          const float* keyop, int ld_key, const float* a, float* gkey, int ld_gkey,
