@@ -92,12 +92,12 @@ _SIGS = {
     "disgat_aux_score": (_c.c_int, [_c.c_int, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
                                     _c.c_int, _P, _c.c_int, _P, _c.c_int, _P, _c.c_int, _P, _P, _P, _P]),
     "disgat_pair_loss": (_c.c_int, [_P, _c.c_int64, _c.c_int, _c.c_int, _P, _P, _P, _P]),
-    "disgat_pair_loss_bwd": (_c.c_int, [_P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _P, _P, _P, _P]),
+    "disgat_pair_loss_bwd": (_c.c_int, [_P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _P, _P, _P, _c.c_int, _P]),
     "disgat_bwd_alpha": (_c.c_int, [_P, _c.c_int, _P, _c.c_int64, _c.c_int, _c.c_int, _P, _c.c_int, _P, _P, _P, _P, _P,
-                                    _P, _P, _c.c_int, _c.c_float, _c.c_uint64, _P, _P]),
+                                    _P, _c.c_int, _P, _c.c_int, _c.c_float, _c.c_uint64, _P, _P]),
     "disgat_seg_grad_att3": (_c.c_int, [_P, _c.c_int, _P, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
                                         _P, _c.c_int, _P, _c.c_int, _P, _P, _c.c_int, _P, _c.c_int, _P, _P]),
-    "disgat_seg_grad_sign": (_c.c_int, [_P, _c.c_int, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P,
+    "disgat_seg_grad_sign": (_c.c_int, [_P, _c.c_int, _P, _P, _c.c_int64, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P,
                                         _P, _c.c_int, _P, _P, _c.c_int, _P, _c.c_int, _c.c_int, _P, _P]),
     "disgat_seg_grad_hx": (_c.c_int, [_c.c_int, _P, _c.c_int, _P, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int,
                                       _c.c_int, _P, _c.c_int, _P, _c.c_int, _c.c_int, _P, _P]),

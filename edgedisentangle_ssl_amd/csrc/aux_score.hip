@@ -285,7 +285,7 @@ __global__ __launch_bounds__(192) void pair_loss_finish_kernel(const double* __r
 // the other rows (coef = upstream gradient x class weight / M, prepared by the host on the device).
 __global__ __launch_bounds__(256) void pair_loss_bwd_kernel(const float* __restrict__ aux, int64_t M, int H, int h_lo, int h_hi,
                                                             const float* __restrict__ labels, const float* __restrict__ coef,
-                                                            float* __restrict__ g) {
+                                                            float* __restrict__ g, int transposed) {
   const float c_pos = coef[0], c_neg = coef[1];
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += stride) {
@@ -294,7 +294,11 @@ __global__ __launch_bounds__(256) void pair_loss_bwd_kernel(const float* __restr
     const float t = labels[m];
     const float p = sigmoidf_(s);
     const float gv = t < 0.f ? 0.f : (t != 0.f ? c_pos : c_neg) * 2.0f * (p - t) * p * (1.0f - p);   // t < 0: padding
-    for (int h = 0; h < H; ++h) g[(int64_t)h * M + m] = (h >= h_lo && h < h_hi) ? gv : 0.f;
+    if (transposed) {        // [M][H]: the H gradients of a pair side by side (what the column-side segment pass gathers)
+      for (int h = 0; h < H; ++h) g[m * H + h] = (h >= h_lo && h < h_hi) ? gv : 0.f;
+    } else {
+      for (int h = 0; h < H; ++h) g[(int64_t)h * M + m] = (h >= h_lo && h < h_hi) ? gv : 0.f;
+    }
   }
 }
 
@@ -416,13 +420,13 @@ extern "C" int disgat_pair_loss(const float* aux, int64_t M, int h_lo, int h_hi,
 }
 
 extern "C" int disgat_pair_loss_bwd(const float* aux, int64_t M, int H, int h_lo, int h_hi, const float* labels,
-                                    const float* coef, float* g, disgat_stream_t stream) {
+                                    const float* coef, float* g, int g_transposed, disgat_stream_t stream) {
   using namespace disgat;
   DISGAT_REQUIRE(aux && labels && coef && g && M >= 0 && H > 0 && h_lo >= 0 && h_hi >= h_lo && h_hi <= H,
                  "pair_loss_bwd: bad arguments");
   if (M == 0) return 0;
   const int grid = (int)min((int64_t)4096, (M + 255) / 256);
   hipLaunchKernelGGL(pair_loss_bwd_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), aux, M, H, h_lo,
-                     h_hi, labels, coef, g);
+                     h_hi, labels, coef, g, g_transposed);
   return check_launch("pair_loss_bwd_kernel");
 }

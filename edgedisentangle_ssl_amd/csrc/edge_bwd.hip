@@ -57,7 +57,8 @@ struct BwdAlphaArgs {
   const float* edge_e;  // [H][E]
   const float* den;     // [N][2][H]: softmax denominators, dropped-out numerator sums
   const float* ge_in;   // [H][E] or null
-  float* ge_out;        // [H][E]
+  float* ge_out;        // [H][E], or [E][H] with ge_t (what the sign-record segment passes gather per position)
+  int ge_t;
   float* beta;          // [H][E]
   int sage_div;
   DropCfg drop;
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void bwd_alpha_kernel(const BwdAlp
         const float gs = alpha * (cf * galk[t] - tsel);
         float g = gs * s * (1.0f - s);
         if (A.ge_in != nullptr) g += A.ge_in[o];
-        A.ge_out[o] = g;
+        A.ge_out[A.ge_t ? k * H + myh : o] = g;      // [E][H]: lane (g', h) -> consecutive floats, one 256-byte run per t
         A.beta[o] = alpha * cf;
       }
     }
@@ -283,8 +284,8 @@ struct SignArgs {
   const int4* items;     // {key, m_begin, m_end, slot} over a list sorted by key
   int n_items;
   const int32_t* perm;   // [M] or null: row of g / sign belonging to list position m
-  const float* g;        // [H][g_stride] upstream gradient of the raw scores
-  int64_t g_stride;
+  const float* g;        // upstream gradient of the raw scores: head h, position p at g[h * g_stride + p * g_pstride]
+  int64_t g_stride, g_pstride;
   int h_lo, h_hi;
   const uint32_t* sign;  // [M][64] sign words (disgat_common.h)
   const float* keyop;    // P (row pass) or Q (column pass); read only when ga_part != null
@@ -334,7 +335,7 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void seg_grad_sign_kernel(const Si
         for (int t = 0; t < 4; ++t) {
           const int64_t pos = __builtin_amdgcn_readlane(pv, (i + t) & 63);
           w[t] = sg[pos * 64];
-          gv[t] = (active && i + t < cnt) ? gh[pos] : 0.f;
+          gv[t] = (active && i + t < cnt) ? gh[pos * A.g_pstride] : 0.f;
         }
       };
       auto accum = [&](const uint32_t(&w)[4], const float(&gv)[4]) {
@@ -510,8 +511,9 @@ __global__ __launch_bounds__(256) void seg_combine_kernel(const int32_t* __restr
 
 extern "C" int disgat_bwd_alpha(const int32_t* items, int n_items, const int32_t* col, int64_t E, int H, int F_in,
                                 const float* x, int ldx, const float* gZ, const float* Z, const float* edge_e,
-                                const float* den, const float* ge_in, float* ge_out, float* beta, int sage_div,
-                                float drop_p, uint64_t drop_seed, const uint64_t* drop_seed_dev, disgat_stream_t stream) {
+                                const float* den, const float* ge_in, float* ge_out, int ge_transposed, float* beta,
+                                int sage_div, float drop_p, uint64_t drop_seed, const uint64_t* drop_seed_dev,
+                                disgat_stream_t stream) {
   using namespace disgat;
   if (n_items == 0 || E == 0) return 0;
   const int hl = ilog2_exact(H);
@@ -521,7 +523,7 @@ extern "C" int disgat_bwd_alpha(const int32_t* items, int n_items, const int32_t
   const int xn = (F_in + 255) / 256;
   DISGAT_REQUIRE(xn == 1 || (xn == 2 && hl <= 3), "bwd_alpha: F_in=%d too wide for H=%d", F_in, H);
   BwdAlphaArgs A{reinterpret_cast<const int4*>(items), n_items, col, E, F_in, x, ldx, gZ, Z, edge_e, den, ge_in,
-                 ge_out, beta, sage_div,
+                 ge_out, ge_transposed != 0, beta, sage_div,
                  DropCfg{drop_seed, (uint32_t)((double)drop_p * 4294967296.0), 1.0f / (1.0f - drop_p), drop_seed_dev}};
   const dim3 grid((n_items + DISGAT_WAVES_PER_BLOCK - 1) / DISGAT_WAVES_PER_BLOCK), block(DISGAT_BLOCK);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -597,7 +599,8 @@ extern "C" int disgat_seg_grad_att3(const int32_t* items, int n_items, const int
 }
 
 extern "C" int disgat_seg_grad_sign(const int32_t* items, int n_items, const int32_t* perm, const float* g,
-                                    int64_t g_stride, int h_lo, int h_hi, int H, int F_out, const uint32_t* sign_bits,
+                                    int64_t g_stride, int64_t g_pos_stride, int h_lo, int h_hi, int H, int F_out,
+                                    const uint32_t* sign_bits,
                                     const float* keyop, int ld_key, const float* a, float* gkey, int ld_gkey,
                                     float* ga_part, int n_waves, int accumulate, float* part, disgat_stream_t stream) {
   using namespace disgat;
@@ -613,7 +616,7 @@ extern "C" int disgat_seg_grad_sign(const int32_t* items, int n_items, const int
                  "seg_grad_sign: strides must be multiples of 4 floats and bases 16-byte aligned");
   DISGAT_REQUIRE(n_waves > 0 && n_waves % DISGAT_WAVES_PER_BLOCK == 0, "seg_grad_sign: n_waves must be a positive multiple of %d", DISGAT_WAVES_PER_BLOCK);
   const int qn = F_out / g4;
-  SignArgs A{reinterpret_cast<const int4*>(items), n_items, perm, g, g_stride, h_lo, h_hi, sign_bits, keyop, ld_key, a,
+  SignArgs A{reinterpret_cast<const int4*>(items), n_items, perm, g, g_stride, g_pos_stride, h_lo, h_hi, sign_bits, keyop, ld_key, a,
              gkey, ld_gkey, ga_part, accumulate, part};
   const dim3 grid(n_waves / DISGAT_WAVES_PER_BLOCK), block(DISGAT_BLOCK);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);

@@ -56,15 +56,25 @@ def _seg_att3(wi, other, perm, g, lo, hi, H, f_out, keyop, otherop, a, n_keys, w
     return gkey, (ga_part.sum(0) if want_ga else None)
 
 
+def _g_strides(g, H):
+    """(tensor to hand to the kernel, head stride, position stride) of a score gradient [H, M]: the [M, H]-backed layout
+    disgat_pair_loss_bwd / disgat_bwd_alpha write for the sign path is taken as it is, anything else made contiguous."""
+    if g.dim() == 2 and g.shape[0] == H and g.stride(0) == 1 and (g.stride(1) == H or g.shape[1] <= 1):
+        return g, 1, H
+    g = g.contiguous()
+    return g, g.stride(0), 1
+
+
 def _seg_sign(wi, perm, g, lo, hi, H, f_out, sign, keyop, a, n_keys, want_ga, into=None):
     """Score backward of one side (rows: keyop = P, columns: keyop = Q) from the forward's sign record.
     Returns (gkey [n_keys, H*f_out], this side's share of grad a or None); `into`: an existing gkey to add into."""
+    g, g_hs, g_ps = _g_strides(g, H)
     dev = g.device
     gkey = _keybuf((n_keys, H * f_out), dev, wi) if into is None else into
     n_waves = min(_MAX_WAVES, (wi.n_items + 3) // 4 * 4)
     ga_part = torch.empty((n_waves, H * f_out), dtype=torch.float32, device=dev) if want_ga else None
     part = _part(wi, gkey)
-    _lib.call("disgat_seg_grad_sign", wi.items.data_ptr(), wi.n_items, ops._ptr(perm), g.data_ptr(), g.stride(0), lo, hi,
+    _lib.call("disgat_seg_grad_sign", wi.items.data_ptr(), wi.n_items, ops._ptr(perm), g.data_ptr(), g_hs, g_ps, lo, hi,
               H, f_out, sign.data_ptr(), ops._ptr(keyop), 0 if keyop is None else keyop.stride(0), ops._ptr(a), gkey.data_ptr(), gkey.stride(0),
               ops._ptr(ga_part), n_waves, int(into is not None), ops._ptr(part), ops._stream())
     _combine(wi, part, gkey, H * f_out, into is not None)
@@ -96,7 +106,7 @@ def edge_backward(ctx, gz, ge, want_ge=False):
     ge_tot = torch.empty((H, e), dtype=torch.float32, device=dev)
     beta = torch.empty((H, e), dtype=torch.float32, device=dev)
     _lib.call("disgat_bwd_alpha", wi.items.data_ptr(), wi.n_items, graph.col.data_ptr(), e, H, f_in, x.data_ptr(),
-              x.stride(0), gz.data_ptr(), z.data_ptr(), edge_e.data_ptr(), den.data_ptr(), ops._ptr(ge), ge_tot.data_ptr(),
+              x.stride(0), gz.data_ptr(), z.data_ptr(), edge_e.data_ptr(), den.data_ptr(), ops._ptr(ge), ge_tot.data_ptr(), 0,
               beta.data_ptr(), int(bool(sage)), float(drop[0]), int(drop[1]), ops._ptr(drop[2] if len(drop) > 2 else None), ops._stream())
     g_x = g_row = g_col = g_a = None
     t = twi = None
@@ -314,15 +324,15 @@ def layer_backward_u(ctx, gz, ge, gaux):
         wi = graph.work_items(chunk)
         gz = torch.zeros_like(z) if gz is None else gz.contiguous()
         ge = None if ge is None else ge.contiguous()
-        ge_tot = torch.empty((H, e), dtype=torch.float32, device=dev)
-        beta = torch.empty((H, e), dtype=torch.float32, device=dev)
+        ge_tot = torch.empty((e, H), dtype=torch.float32, device=dev).t()     # [H, E] backed by [E, H]: both segment passes
+        beta = torch.empty((H, e), dtype=torch.float32, device=dev)            # read a position's H gradients as one 32-byte run
         _lib.call("disgat_bwd_alpha", wi.items.data_ptr(), wi.n_items, graph.col.data_ptr(), e, H, f_in, x.data_ptr(),
-                  x.stride(0), gz.data_ptr(), z.data_ptr(), edge_e.data_ptr(), den.data_ptr(), ops._ptr(ge), ge_tot.data_ptr(),
+                  x.stride(0), gz.data_ptr(), z.data_ptr(), edge_e.data_ptr(), den.data_ptr(), ops._ptr(ge), ge_tot.data_ptr(), 1,
                   beta.data_ptr(), int(bool(sage)), float(drop[0]), int(drop[1]), ops._ptr(drop[2] if len(drop) > 2 else None), ops._stream())
         t = graph.transpose()
         twi = t.work_items(chunk)
-    live = [(pairs, rng, sg, go.contiguous()) for pairs, rng, sg, go in zip(lists, ranges, ctx.aux_signs, gaux)
-            if go is not None and sg is not None]
+    live = [(pairs, rng, sg, go) for pairs, rng, sg, go in zip(lists, ranges, ctx.aux_signs, gaux)
+            if go is not None and sg is not None]          # [H, M], possibly [M, H]-backed (_g_strides)
     g_a = None
 
     def dense_side(x_in, w, u, am, need_in, need_w):

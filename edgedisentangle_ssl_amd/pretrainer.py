@@ -72,11 +72,13 @@ class _PairLoss(torch.autograd.Function):
         base, labels, neg_w, m = ctx.saved_tensors
         h_lo, h_hi = ctx.rng
         coef = (torch.stack([torch.ones_like(neg_w), neg_w]) * (gout.double() / m)).to(torch.float32).contiguous()
-        g = torch.empty_like(base)
+        # [H, M] gradient backed by an [M, H] buffer: the segment passes of the score backward (ops_bwd._g_strides) then find
+        # a pair's H values in one 32-byte run - the column-side pass visits the pairs in column order, i.e. at random
+        g = torch.empty((base.shape[1], base.shape[0]), dtype=base.dtype, device=base.device)
         from . import _lib
         _lib.call("disgat_pair_loss_bwd", base.data_ptr(), int(base.shape[1]), int(base.shape[0]), h_lo, h_hi,
-                  labels.data_ptr(), coef.data_ptr(), g.data_ptr(), ops._stream())
-        return g, None, None, None, None
+                  labels.data_ptr(), coef.data_ptr(), g.data_ptr(), 1, ops._stream())
+        return g.t(), None, None, None, None
 
 
 def pair_mse_loss(aux, h_lo, h_hi, labels, graph=None):

@@ -125,16 +125,19 @@ int disgat_pair_loss(const float* aux, int64_t M, int h_lo, int h_hi, const floa
 /* ---- backward -------------------------------------------------------------------------- */
 
 /* Gradient of that loss w.r.t. the raw scores: g[h][m] = coef[labels[m] != 0 ? 0 : 1] * 2 (p - t) p (1 - p) for h in
- * [h_lo, h_hi), 0 for the other of the H rows; coef = 2 device floats (upstream gradient x class weight / M). */
+ * [h_lo, h_hi), 0 for the other of the H rows; coef = 2 device floats (upstream gradient x class weight / M).
+ * g_transposed != 0: g is written as [M][H] (g[m][h]) - the layout in which disgat_seg_grad_sign's column-side pass,
+ * which visits the pairs in column order, finds the H gradients of a pair in one 32-byte run instead of H sectors. */
 int disgat_pair_loss_bwd(const float* aux, int64_t M, int H, int h_lo, int h_hi, const float* labels,
-                         const float* coef, float* g, disgat_stream_t stream);
+                         const float* coef, float* g, int g_transposed, disgat_stream_t stream);
 
 /* Per edge and head: ge_out = ge_in + d(loss)/d(e) through softmax-of-sigmoid given gZ (grad of Z),
  * and beta = alpha*sc, the coefficient of x[col] in Z (used by the transposed pass for grad x).
- * ge_in may be NULL.  Items/col as in disgat_edge_fwd; Z, den, edge_e are the forward's outputs. */
+ * ge_in may be NULL.  Items/col as in disgat_edge_fwd; Z, den, edge_e are the forward's outputs.
+ * ge_transposed != 0: ge_out is written as [E][H] (see disgat_pair_loss_bwd); ge_in and beta stay [H][E]. */
 int disgat_bwd_alpha(const int32_t* items, int n_items, const int32_t* col, int64_t E, int H, int F_in,
                      const float* x, int ldx, const float* gZ, const float* Z, const float* edge_e,
-                     const float* den, const float* ge_in, float* ge_out, float* beta, int sage_div,
+                     const float* den, const float* ge_in, float* ge_out, int ge_transposed, float* beta, int sage_div,
                      float drop_p, uint64_t drop_seed, const uint64_t* drop_seed_dev, disgat_stream_t stream);
 
 /* Segment gradient of the att-3 score e = sum_f a_f lrelu(keyop[key] + otherop[other]).
@@ -158,11 +161,13 @@ int disgat_seg_grad_att3(const int32_t* items, int n_items, const int32_t* other
  * because lrelu(z) = lrelu'(z) * (P + Q).  Reads 64 words + H floats per list position.
  * accumulate = 1 adds into gkey instead (several lists scoring against the same operands share one gradient buffer;
  * columns of heads outside [h_lo, h_hi) are then left untouched).
+ * g: head h of list position p at g[h * g_stride + p * g_pos_stride] ([H][M]: strides (M, 1); [M][H]: (1, H)).
  * a == NULL: gkey receives u itself.  With keyop = x W the operand's producer then needs no operand row at all:
  * G = x^T u is the weight-gradient GEMM that runs anyway, grad W = G (.) a (per column), grad a = sum_rows W (.) G,
  * grad x = u (W (.) a)^T. */
 int disgat_seg_grad_sign(const int32_t* items, int n_items, const int32_t* perm, const float* g,
-                         int64_t g_stride, int h_lo, int h_hi, int H, int F_out, const uint32_t* sign_bits,
+                         int64_t g_stride, int64_t g_pos_stride, int h_lo, int h_hi, int H, int F_out,
+                         const uint32_t* sign_bits,
                          const float* keyop, int ld_key, const float* a, float* gkey, int ld_gkey,
                          float* ga_part, int n_waves, int accumulate, float* part, disgat_stream_t stream);
 
