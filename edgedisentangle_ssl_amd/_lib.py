@@ -98,10 +98,10 @@ _SIGS = {
     "disgat_seg_grad_att3": (_c.c_int, [_P, _c.c_int, _P, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
                                         _P, _c.c_int, _P, _c.c_int, _P, _P, _c.c_int, _P, _c.c_int, _P, _P]),
     "disgat_seg_grad_sign": (_c.c_int, [_P, _c.c_int, _P, _P, _c.c_int64, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P,
-                                        _P, _c.c_int, _P, _P, _c.c_int, _P, _c.c_int, _c.c_int, _P, _P]),
+                                        _P, _c.c_int, _P, _P, _c.c_int, _P, _c.c_int, _c.c_int, _P, _P, _P]),
     "disgat_seg_grad_hx": (_c.c_int, [_c.c_int, _P, _c.c_int, _P, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int,
                                       _c.c_int, _P, _c.c_int, _P, _c.c_int, _c.c_int, _P, _P]),
-    "disgat_seg_combine": (_c.c_int, [_P, _P, _c.c_int, _c.c_int, _P, _P, _c.c_int, _c.c_int, _P]),
+    "disgat_seg_combine": (_c.c_int, [_P, _P, _c.c_int, _c.c_int, _P, _P, _c.c_int, _c.c_int, _P, _P]),
     "disgat_gemm_split": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _P, _P, _P, _c.c_int64, _c.c_int64, _P, _c.c_int64,
                                      _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_float,
                                      _c.c_int, _P]),

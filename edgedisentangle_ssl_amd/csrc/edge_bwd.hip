@@ -43,6 +43,18 @@ __device__ __forceinline__ void out4(float* p, f32x4 v, bool atomic, bool accumu
   }
 }
 
+// max |v| bookkeeping for the buffers the segment passes produce (the f16x3 GEMMs that consume them need max |.| as their
+// scale input; measuring it in the producer saves a pass over the 8 GB buffer).  Bit patterns of non-negative floats order
+// like unsigned integers.
+__device__ __forceinline__ uint32_t amax4(uint32_t m, const f32x4 v) {
+  return max(max(m, __float_as_uint(fabsf(v.x))), max(__float_as_uint(fabsf(v.y)), max(__float_as_uint(fabsf(v.z)), __float_as_uint(fabsf(v.w)))));
+}
+__device__ __forceinline__ void wave_atomic_max(uint32_t m, uint32_t* out) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+  if ((threadIdx.x & 63) == 0 && m > __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out, m);
+}
+
 // ------------------------------------------------------------------------------------------
 struct BwdAlphaArgs {
   const int4* items;
@@ -296,6 +308,7 @@ struct SignArgs {
   float* ga_part;        // [n_waves][H*FQ] or null
   int accumulate;        // 1: add into gkey (heads outside [h_lo, h_hi) are left untouched) instead of storing
   float* part;           // [n_slots][ld_gkey] partial records of split keys, or null (atomics)
+  uint32_t* amax_out;    // or null: raised to max |value stored into gkey| (whole keys; split keys: disgat_seg_combine)
 };
 
 template <int HL, int QN>
@@ -316,6 +329,7 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void seg_grad_sign_kernel(const Si
   f32x4 ga[QN];
 #pragma unroll
   for (int j = 0; j < QN; ++j) ga[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  uint32_t mx = 0u;
 
   for (int item = wave; item < A.n_items; item += n_waves) {   // persistent: ga stays in registers
     const int4 it = A.items[item];
@@ -365,10 +379,20 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void seg_grad_sign_kernel(const Si
     for (int j = 0; j < QN; ++j) {           // a (8 KB, cache-resident) and the key's operand row are read here, once per item
       const f32x4 u = 0.99f * up[j] + base;
       if (want_ga) ga[j] += ld4(pp + j * G * 4) * u;
-      if (to_part || !A.accumulate || active)
-        out4(op + j * G * 4, A.a ? ld4(A.a + qoff + j * G * 4) * u : u, slot >= 0 && !to_part, A.accumulate != 0 && !to_part);
+      if (to_part || !A.accumulate || active) {
+        const f32x4 val = A.a ? ld4(A.a + qoff + j * G * 4) * u : u;
+        if (A.amax_out != nullptr && slot < 0) {       // whole key: the value that ends up in gkey is known here
+          float* q = op + j * G * 4;
+          const f32x4 fin = A.accumulate ? ld4(q) + val : val;
+          st4(q, fin);
+          mx = amax4(mx, fin);
+        } else {
+          out4(op + j * G * 4, val, slot >= 0 && !to_part, A.accumulate != 0 && !to_part);
+        }
+      }
     }
   }
+  if (A.amax_out != nullptr) wave_atomic_max(mx, A.amax_out);     // once per wave of a persistent launch
   if (want_ga) {
     float* gp = A.ga_part + (size_t)wave * (FQ << HL) + qoff;
 #pragma unroll
@@ -491,16 +515,19 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void seg_grad_hx_col_kernel(const 
 // gkey[key][0:width] (+)= sum of the key's partial records, in slice order: one block per split key.
 __global__ __launch_bounds__(256) void seg_combine_kernel(const int32_t* __restrict__ split_keys, const int32_t* __restrict__ split_ptr,
                                                           int width, const float* __restrict__ part, int ld, float* __restrict__ gkey,
-                                                          int accumulate) {
+                                                          int accumulate, uint32_t* __restrict__ amax_out) {
   const int key = split_keys[blockIdx.x];
   if (key < 0) return;              // padding entry of a fixed-capacity split table
   const int s0 = split_ptr[blockIdx.x], s1 = split_ptr[blockIdx.x + 1];
   float* out = gkey + (size_t)key * ld;
+  uint32_t mx = 0u;
   for (int c = threadIdx.x * 4; c < width; c += 256 * 4) {
     f32x4 acc = accumulate ? ld4(out + c) : f32x4{0.f, 0.f, 0.f, 0.f};
     for (int sl = s0; sl < s1; ++sl) acc += ld4(part + (size_t)sl * ld + c);
     st4(out + c, acc);
+    mx = amax4(mx, acc);
   }
+  if (amax_out != nullptr) wave_atomic_max(mx, amax_out);
 }
 
 }  // namespace disgat
@@ -602,7 +629,8 @@ extern "C" int disgat_seg_grad_sign(const int32_t* items, int n_items, const int
                                     int64_t g_stride, int64_t g_pos_stride, int h_lo, int h_hi, int H, int F_out,
                                     const uint32_t* sign_bits,
                                     const float* keyop, int ld_key, const float* a, float* gkey, int ld_gkey,
-                                    float* ga_part, int n_waves, int accumulate, float* part, disgat_stream_t stream) {
+                                    float* ga_part, int n_waves, int accumulate, float* part, float* amax_out,
+                                    disgat_stream_t stream) {
   using namespace disgat;
   if (n_items == 0) return 0;
   const int hl = ilog2_exact(H);
@@ -617,7 +645,7 @@ extern "C" int disgat_seg_grad_sign(const int32_t* items, int n_items, const int
   DISGAT_REQUIRE(n_waves > 0 && n_waves % DISGAT_WAVES_PER_BLOCK == 0, "seg_grad_sign: n_waves must be a positive multiple of %d", DISGAT_WAVES_PER_BLOCK);
   const int qn = F_out / g4;
   SignArgs A{reinterpret_cast<const int4*>(items), n_items, perm, g, g_stride, g_pos_stride, h_lo, h_hi, sign_bits, keyop, ld_key, a,
-             gkey, ld_gkey, ga_part, accumulate, part};
+             gkey, ld_gkey, ga_part, accumulate, part, reinterpret_cast<uint32_t*>(amax_out)};
   const dim3 grid(n_waves / DISGAT_WAVES_PER_BLOCK), block(DISGAT_BLOCK);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 #define DISGAT_SS(HL_, QN_) hipLaunchKernelGGL((seg_grad_sign_kernel<HL_, QN_>), grid, block, 0, s, A)
@@ -686,13 +714,14 @@ extern "C" int disgat_seg_grad_hx(int col_mode, const int32_t* items, int n_item
 }
 
 extern "C" int disgat_seg_combine(const int32_t* split_keys, const int32_t* split_ptr, int n_split, int width,
-                                  const float* part, float* gkey, int ld_gkey, int accumulate, disgat_stream_t stream) {
+                                  const float* part, float* gkey, int ld_gkey, int accumulate, float* amax_out,
+                                  disgat_stream_t stream) {
   using namespace disgat;
   if (n_split == 0) return 0;
   DISGAT_REQUIRE(split_keys && split_ptr && part && gkey, "seg_combine: null pointer");
   DISGAT_REQUIRE(width > 0 && width % 4 == 0 && width <= ld_gkey && ld_gkey % 4 == 0 && aligned16(part) && aligned16(gkey),
                  "seg_combine: width / stride must be multiples of 4 floats (width <= stride), bases 16-byte aligned");
   hipLaunchKernelGGL(seg_combine_kernel, dim3(n_split), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), split_keys,
-                     split_ptr, width, part, ld_gkey, gkey, accumulate);
+                     split_ptr, width, part, ld_gkey, gkey, accumulate, reinterpret_cast<uint32_t*>(amax_out));
   return check_launch("seg_combine_kernel");
 }

@@ -37,10 +37,10 @@ def _part(wi, gkey):
     return torch.empty((wi.n_slots, gkey.stride(0)), dtype=torch.float32, device=gkey.device)
 
 
-def _combine(wi, part, gkey, width, accumulate):
+def _combine(wi, part, gkey, width, accumulate, amax_out=None):
     if part is not None:
         _lib.call("disgat_seg_combine", wi.split_rows.data_ptr(), wi.split_ptr.data_ptr(), wi.n_split, width,
-                  part.data_ptr(), gkey.data_ptr(), gkey.stride(0), int(bool(accumulate)), ops._stream())
+                  part.data_ptr(), gkey.data_ptr(), gkey.stride(0), int(bool(accumulate)), ops._ptr(amax_out), ops._stream())
 
 
 def _seg_att3(wi, other, perm, g, lo, hi, H, f_out, keyop, otherop, a, n_keys, want_ga):
@@ -65,7 +65,7 @@ def _g_strides(g, H):
     return g, g.stride(0), 1
 
 
-def _seg_sign(wi, perm, g, lo, hi, H, f_out, sign, keyop, a, n_keys, want_ga, into=None):
+def _seg_sign(wi, perm, g, lo, hi, H, f_out, sign, keyop, a, n_keys, want_ga, into=None, amax_out=None):
     """Score backward of one side (rows: keyop = P, columns: keyop = Q) from the forward's sign record.
     Returns (gkey [n_keys, H*f_out], this side's share of grad a or None); `into`: an existing gkey to add into."""
     g, g_hs, g_ps = _g_strides(g, H)
@@ -76,8 +76,9 @@ def _seg_sign(wi, perm, g, lo, hi, H, f_out, sign, keyop, a, n_keys, want_ga, in
     part = _part(wi, gkey)
     _lib.call("disgat_seg_grad_sign", wi.items.data_ptr(), wi.n_items, ops._ptr(perm), g.data_ptr(), g_hs, g_ps, lo, hi,
               H, f_out, sign.data_ptr(), ops._ptr(keyop), 0 if keyop is None else keyop.stride(0), ops._ptr(a), gkey.data_ptr(), gkey.stride(0),
-              ops._ptr(ga_part), n_waves, int(into is not None), ops._ptr(part), ops._stream())
-    _combine(wi, part, gkey, H * f_out, into is not None)
+              ops._ptr(ga_part), n_waves, int(into is not None), ops._ptr(part),
+              ops._ptr(amax_out if (part is not None or wi.n_split == 0) else None), ops._stream())
+    _combine(wi, part, gkey, H * f_out, into is not None, amax_out)
     return gkey, (ga_part.sum(0) if want_ga else None)
 
 
@@ -335,14 +336,15 @@ def layer_backward_u(ctx, gz, ge, gaux):
             if go is not None and sg is not None]          # [H, M], possibly [M, H]-backed (_g_strides)
     g_a = None
 
-    def dense_side(x_in, w, u, am, need_in, need_w):
-        """(grad x_in, grad w, this side's share of grad a) from u [rows, H*F_out]."""
+    def dense_side(x_in, w, u, am, need_in, need_w, u_amax):
+        """(grad x_in, grad w, this side's share of grad a) from u [rows, H*F_out]; u_amax: the bound on |u| the segment
+        passes kept while storing it (max over everything they stored, so >= max |u|), or None."""
         nonlocal g_a
         if u is None:
             return None, None
         with torch.no_grad():
             g_in, G = ops_gemm.linear_backward(x_in.detach(), (w.detach() * a.detach()) if need_in else w.detach(), u, am,
-                                               need_in, need_w or need_a)
+                                               need_in, need_w or need_a, g_amax=u_amax)
             g_w = None
             if G is not None:
                 if need_a:
@@ -354,27 +356,29 @@ def layer_backward_u(ctx, gz, ge, gaux):
 
     # ---- row side
     u = None
+    bound = torch.zeros(2, dtype=torch.float32, device=dev) if DETERMINISTIC else None     # [row side, column side] max |u|
+    b_row, b_col = (bound[0:1], bound[1:2]) if bound is not None else (None, None)
     if need_xp or need_wt or need_a:
         if have_edge:
-            u, _ = _seg_sign(wi, None, ge_tot, 0, H, H, f_out, ctx.sign, None, None, n, False)
+            u, _ = _seg_sign(wi, None, ge_tot, 0, H, H, f_out, ctx.sign, None, None, n, False, amax_out=b_row)
         for pairs, (lo, hi), sg, gout in live:
             wl, _perm, perm32 = _segments_of(pairs, 0, n_rows, ops.chunk_small(att, int(pairs.shape[1]), H))
-            u, _ = _seg_sign(wl, perm32, gout, lo, hi, H, f_out, sg, None, None, n_rows, False, into=u)
-    g_xp, g_wt = dense_side(x_p, w_top, u, am_p, need_xp, need_wt)
+            u, _ = _seg_sign(wl, perm32, gout, lo, hi, H, f_out, sg, None, None, n_rows, False, into=u, amax_out=b_row)
+    g_xp, g_wt = dense_side(x_p, w_top, u, am_p, need_xp, need_wt, b_row)
     u = None
     # ---- column side; every record is dead after its column pass
     if need_xq or need_wb or need_a:
         if have_edge:
-            u, _ = _seg_sign(twi, t.eid, ge_tot, 0, H, H, f_out, ctx.sign, None, None, n_cols, False)
+            u, _ = _seg_sign(twi, t.eid, ge_tot, 0, H, H, f_out, ctx.sign, None, None, n_cols, False, amax_out=b_col)
         ctx.sign = None
         for li, (pairs, (lo, hi), sg, gout) in enumerate(live):
             wl, _perm, perm32 = _segments_of(pairs, 1, n_cols, ops.chunk_small(att, int(pairs.shape[1]), H))
-            u, _ = _seg_sign(wl, perm32, gout, lo, hi, H, f_out, sg, None, None, n_cols, False, into=u)
+            u, _ = _seg_sign(wl, perm32, gout, lo, hi, H, f_out, sg, None, None, n_cols, False, into=u, amax_out=b_col)
             live[li] = None
             sg = None
     ctx.sign = None
     ctx.aux_signs = [None] * len(ctx.aux_signs)
-    g_xq, g_wb = dense_side(x_q, w_bot, u, am_q, need_xq, need_wb)
+    g_xq, g_wb = dense_side(x_q, w_bot, u, am_q, need_xq, need_wb, b_col)
     u = None
     g_x = None
     if have_edge and need_x:

@@ -276,11 +276,12 @@ def _weight_grad(a, g, a_amax, g_amax):
     return out if batched else out[0]
 
 
-def linear_backward(a, w, g, a_amax=None, need_a=True, need_w=True):
-    """(grad a, grad w) of a @ w (2-D, no bias / activation) on the f16x3 kernels where their tiling allows."""
+def linear_backward(a, w, g, a_amax=None, need_a=True, need_w=True, g_amax=None):
+    """(grad a, grad w) of a @ w (2-D, no bias / activation) on the f16x3 kernels where their tiling allows.
+    g_amax: max |g| (or an upper bound) as a device scalar when the producer of g measured it already."""
     g_am = None
     if mode() == "f16x3" and g.is_cuda and g.dim() == 2 and g.is_contiguous() and g.shape[1] % 4 == 0 and g.data_ptr() % 16 == 0:
-        g_am = amax(g)
+        g_am = g_amax if g_amax is not None else amax(g)
     ga = gw = None
     if need_a:
         ga = _forward(g, w.t(), None, None, ACT_NONE, 0.0, g_am)

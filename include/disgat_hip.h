@@ -162,6 +162,8 @@ int disgat_seg_grad_att3(const int32_t* items, int n_items, const int32_t* other
  * accumulate = 1 adds into gkey instead (several lists scoring against the same operands share one gradient buffer;
  * columns of heads outside [h_lo, h_hi) are then left untouched).
  * g: head h of list position p at g[h * g_stride + p * g_pos_stride] ([H][M]: strides (M, 1); [M][H]: (1, H)).
+ * amax_out (or NULL): a device float the caller zeroed, raised to max |value stored into gkey| over whole keys (split keys:
+ * disgat_seg_combine's amax_out) - the scale input of the f16x3 GEMMs that consume gkey, measured without another pass.
  * a == NULL: gkey receives u itself.  With keyop = x W the operand's producer then needs no operand row at all:
  * G = x^T u is the weight-gradient GEMM that runs anyway, grad W = G (.) a (per column), grad a = sum_rows W (.) G,
  * grad x = u (W (.) a)^T. */
@@ -169,7 +171,8 @@ int disgat_seg_grad_sign(const int32_t* items, int n_items, const int32_t* perm,
                          int64_t g_stride, int64_t g_pos_stride, int h_lo, int h_hi, int H, int F_out,
                          const uint32_t* sign_bits,
                          const float* keyop, int ld_key, const float* a, float* gkey, int ld_gkey,
-                         float* ga_part, int n_waves, int accumulate, float* part, disgat_stream_t stream);
+                         float* ga_part, int n_waves, int accumulate, float* part, float* amax_out,
+                         disgat_stream_t stream);
 
 /* col_mode = 0: gkey[key][h][:] = sum_m coef[h][perm(m)] * otherop[other_m][:]          (F floats per row)
  * col_mode = 1: gkey[key][:] (+)= sum_m sum_h coef[h][perm(m)] * otherop[other_m][h][:]  (otherop rows H*F) */
@@ -182,9 +185,11 @@ int disgat_seg_grad_hx(int col_mode, const int32_t* items, int n_items, const in
  * given to the three segment launchers above, every slice stores its partial result in part[slot] instead of adding
  * to gkey with float atomics, and this launcher then forms gkey[key][0:width] (+)= sum of the key's slices in slice
  * order - run-to-run deterministic gradients.  split_keys [n_split], split_ptr [n_split+1] as in disgat_edge_combine.
- * part == NULL in the launchers above keeps the atomic path (gkey rows of split keys must then be zeroed by the host). */
+ * part == NULL in the launchers above keeps the atomic path (gkey rows of split keys must then be zeroed by the host).
+ * amax_out (or NULL): raised to max |value stored| as in disgat_seg_grad_sign. */
 int disgat_seg_combine(const int32_t* split_keys, const int32_t* split_ptr, int n_split, int width,
-                       const float* part, float* gkey, int ld_gkey, int accumulate, disgat_stream_t stream);
+                       const float* part, float* gkey, int ld_gkey, int accumulate, float* amax_out,
+                       disgat_stream_t stream);
 
 /* ---- dense contractions --------------------------------------------------------------------- */
 
