@@ -134,12 +134,18 @@ __device__ __forceinline__ float dot4_lrelu_sign(const f32x4 a, const f32x4 p, c
   z = p.w + q.w; acc = fmaf(a.w, lrelu001(z), acc); s.b3 = sign_push(s.b3, z);
   return acc;
 }
-// the 4 components of float4 group j of a sign word as 0.0 / 1.0
+// the 4 components of float4 group j of a sign word as 0.0 / SIGN_UNIT: the 0 / 1 bytes are read as fp8 - 0x01 is the
+// smallest subnormal, a power of two - so that gfx950's packed converts turn TWO bytes into two floats per instruction
+// (v_cvt_pk_f32_fp8 on the low half, its SDWA form on the high half): 2 converts per float4 group instead of 4
+// v_cvt_f32_ubyteN.  The caller divides the accumulated sum by sign_unit() once per key (exact: a power of two).
+__device__ __forceinline__ float sign_unit() { return __builtin_amdgcn_cvt_pk_f32_fp8(0x00000001, false)[0]; }
 template <int QN>
 __device__ __forceinline__ f32x4 sign_floats(uint32_t w, int j) {
   uint32_t t = (w >> (QN - 1 - j)) & 0x01010101u;
   asm("" : "+v"(t));   // opaque: otherwise the bytes are re-derived as single-bit extracts (shift + and + cvt each)
-  return f32x4{(float)(t & 0xffu), (float)((t >> 8) & 0xffu), (float)((t >> 16) & 0xffu), (float)(t >> 24)};
+  const auto lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)t, false);
+  const auto hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)t, true);
+  return f32x4{lo[0], lo[1], hi[0], hi[1]};
 }
 
 __device__ __forceinline__ float dot4(const f32x4 a, const f32x4 b, float acc) {

@@ -330,6 +330,7 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void seg_grad_sign_kernel(const Si
 #pragma unroll
   for (int j = 0; j < QN; ++j) ga[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   uint32_t mx = 0u;
+  const float k99 = 0.99f / sign_unit();       // the record bits arrive as 0 / sign_unit() (a power of two): undone here
 
   for (int item = wave; item < A.n_items; item += n_waves) {   // persistent: ga stays in registers
     const int4 it = A.items[item];
@@ -358,7 +359,7 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void seg_grad_sign_kernel(const Si
           __builtin_amdgcn_sched_barrier(0);      // one position at a time: keeps the 32 bit->float temporaries from piling up
           gall += gv[t];
 #pragma unroll
-          for (int j = 0; j < QN; ++j) up[j] += gv[t] * sign_floats<QN>(w[t], j);   // shift, and, 4 v_cvt_f32_ubyteN, 2 v_pk_fma_f32
+          for (int j = 0; j < QN; ++j) up[j] += gv[t] * sign_floats<QN>(w[t], j);   // shift, and, 2 v_cvt_pk_f32_fp8, 2 v_pk_fma_f32
         }
       };
       uint32_t wA[4], wB[4];
@@ -377,7 +378,7 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void seg_grad_sign_kernel(const Si
     const float* pp = A.keyop + (size_t)key * A.ld_key + qoff;
 #pragma unroll
     for (int j = 0; j < QN; ++j) {           // a (8 KB, cache-resident) and the key's operand row are read here, once per item
-      const f32x4 u = 0.99f * up[j] + base;
+      const f32x4 u = k99 * up[j] + base;
       if (want_ga) ga[j] += ld4(pp + j * G * 4) * u;
       if (to_part || !A.accumulate || active) {
         const f32x4 val = A.a ? ld4(A.a + qoff + j * G * 4) * u : u;
