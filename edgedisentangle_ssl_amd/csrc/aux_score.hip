@@ -91,7 +91,7 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void aux_att3_kernel(const AuxArgs
     } else if constexpr (SIGN) {
       SignAcc sg;
 #pragma unroll
-      for (int j = 0; j < QN; ++j) acc = dot4_lrelu_sign(a_r[j], p_r[j], q[j], acc, sg);
+      for (int j = 0; j < QN; ++j) acc = dot4_lrelu_sign(a_r[j], p_r[j], q[j], acc, sg, j);
       // every lane stores (whole 64-word rows; the words of unscored heads are never read): a store under
       // `active` also splits the block and costs a second v_max per feature (z no longer known canonical)
       A.sign[(m0 + i) * 64 + lane] = sg.word();

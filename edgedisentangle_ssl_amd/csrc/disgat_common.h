@@ -109,9 +109,13 @@ __device__ __forceinline__ float dot4_lrelu(const f32x4 a, const f32x4 p, const 
 // (edge_bwd.hip: seg_grad_sign_kernel).
 //
 // Record of one (edge | pair): 64 uint32 words in lane order.  Lane (h,g) owns features h*F_out + (j*G+g)*4 + k
-// (j < QN float4 groups, k < 4 components); its word keeps component k in byte k and group j at bit QN-1-j of
-// that byte: bit 8*k + QN-1-j.  Byte-per-component lets the backward turn 4 bits into 4 floats with one shift,
-// one and (0x01010101) and four v_cvt_f32_ubyteN.
+// (j < QN float4 groups, k < 4 components).  Its word is eight NIBBLES: nibble k + 4*(j & 1) holds component k of the
+// even (j & 1 = 0) or odd groups, group pair p = j >> 1 at bit QH-1-p of the nibble (QH = max(1, QN/2) <= 4):
+//     bit 4*(k + 4*(j & 1)) + QH-1-(j >> 1).
+// One shift and one and (0x11111111) then isolate the 8 bits of a group pair as eight 0 / 1 nibbles, which gfx950's
+// v_cvt_scalef32_pk_f32_fp4 reads as fp4 values (0x1 = 0.5) and turns into floats two per instruction: 6 VALU ops per 8
+// features in front of the 4 v_pk_fma_f32 that accumulate them (round 2's byte-per-component layout with
+// v_cvt_f32_ubyteN: 12).
 //
 // sign_push: shift left and append (z > 0).  z > 0 as an integer test on the float's bits s: s > 0 as int32
 // (negative floats and -0.0 carry the sign bit, +0.0 is 0), i.e. the sign bit of the saturating 0 - s
@@ -121,31 +125,38 @@ __device__ __forceinline__ uint32_t sign_push(uint32_t bits, float z) {
   return __builtin_amdgcn_alignbit(bits, (uint32_t)t, 31);
 }
 struct SignAcc {
-  uint32_t b0 = 0u, b1 = 0u, b2 = 0u, b3 = 0u;
-  __device__ __forceinline__ uint32_t word() const { return b0 | (b1 << 8) | (b2 << 16) | (b3 << 24); }
+  uint32_t n[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};       // one accumulator per nibble: a group pair's bit per push
+  __device__ __forceinline__ uint32_t word() const {
+    return n[0] | (n[1] << 4) | (n[2] << 8) | (n[3] << 12) | (n[4] << 16) | (n[5] << 20) | (n[6] << 24) | (n[7] << 28);
+  }
 };
-// dot4_lrelu that also pushes the 4 signs (kept scalar per feature: routed through a float4 temporary the
-// compiler forgets that z is the canonical result of an add and spends a second v_max per feature on fmaxf)
-__device__ __forceinline__ float dot4_lrelu_sign(const f32x4 a, const f32x4 p, const f32x4 q, float acc, SignAcc& s) {
+// dot4_lrelu that also pushes the 4 signs of float4 group j (a compile-time index after unrolling; kept scalar per
+// feature: routed through a float4 temporary the compiler forgets that z is the canonical result of an add and spends a
+// second v_max per feature on fmaxf)
+__device__ __forceinline__ float dot4_lrelu_sign(const f32x4 a, const f32x4 p, const f32x4 q, float acc, SignAcc& s, int j) {
+  const int o = 4 * (j & 1);
   float z;
-  z = p.x + q.x; acc = fmaf(a.x, lrelu001(z), acc); s.b0 = sign_push(s.b0, z);
-  z = p.y + q.y; acc = fmaf(a.y, lrelu001(z), acc); s.b1 = sign_push(s.b1, z);
-  z = p.z + q.z; acc = fmaf(a.z, lrelu001(z), acc); s.b2 = sign_push(s.b2, z);
-  z = p.w + q.w; acc = fmaf(a.w, lrelu001(z), acc); s.b3 = sign_push(s.b3, z);
+  z = p.x + q.x; acc = fmaf(a.x, lrelu001(z), acc); s.n[o + 0] = sign_push(s.n[o + 0], z);
+  z = p.y + q.y; acc = fmaf(a.y, lrelu001(z), acc); s.n[o + 1] = sign_push(s.n[o + 1], z);
+  z = p.z + q.z; acc = fmaf(a.z, lrelu001(z), acc); s.n[o + 2] = sign_push(s.n[o + 2], z);
+  z = p.w + q.w; acc = fmaf(a.w, lrelu001(z), acc); s.n[o + 3] = sign_push(s.n[o + 3], z);
   return acc;
 }
-// the 4 components of float4 group j of a sign word as 0.0 / SIGN_UNIT: the 0 / 1 bytes are read as fp8 - 0x01 is the
-// smallest subnormal, a power of two - so that gfx950's packed converts turn TWO bytes into two floats per instruction
-// (v_cvt_pk_f32_fp8 on the low half, its SDWA form on the high half): 2 converts per float4 group instead of 4
-// v_cvt_f32_ubyteN.  The caller divides the accumulated sum by sign_unit() once per key (exact: a power of two).
-__device__ __forceinline__ float sign_unit() { return __builtin_amdgcn_cvt_pk_f32_fp8(0x00000001, false)[0]; }
+// The record bits of group pair p (groups 2p and 2p+1) of a sign word as 0.0 / sign_unit(): ev = group 2p, od = group 2p+1.
+__device__ __forceinline__ float sign_unit() { return __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(0x00000001u, 1.0f, 0)[0]; }
 template <int QN>
-__device__ __forceinline__ f32x4 sign_floats(uint32_t w, int j) {
-  uint32_t t = (w >> (QN - 1 - j)) & 0x01010101u;
-  asm("" : "+v"(t));   // opaque: otherwise the bytes are re-derived as single-bit extracts (shift + and + cvt each)
-  const auto lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)t, false);
-  const auto hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)t, true);
-  return f32x4{lo[0], lo[1], hi[0], hi[1]};
+__device__ __forceinline__ void sign_floats2(uint32_t w, int p, f32x4& ev, f32x4& od) {
+  constexpr int QH = QN >= 2 ? QN / 2 : 1;
+  uint32_t t = (w >> (QH - 1 - p)) & 0x11111111u;
+  asm("" : "+v"(t));   // opaque: otherwise the nibbles are re-derived as single-bit extracts (shift + and + cvt each)
+  const auto e0 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(t, 1.0f, 0);
+  const auto e1 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(t, 1.0f, 1);
+  ev = f32x4{e0[0], e0[1], e1[0], e1[1]};
+  if (QN >= 2) {
+    const auto o0 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(t, 1.0f, 2);
+    const auto o1 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(t, 1.0f, 3);
+    od = f32x4{o0[0], o0[1], o1[0], o1[1]};
+  }
 }
 
 __device__ __forceinline__ float dot4(const f32x4 a, const f32x4 b, float acc) {

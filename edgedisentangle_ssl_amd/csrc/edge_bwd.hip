@@ -359,7 +359,12 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void seg_grad_sign_kernel(const Si
           __builtin_amdgcn_sched_barrier(0);      // one position at a time: keeps the 32 bit->float temporaries from piling up
           gall += gv[t];
 #pragma unroll
-          for (int j = 0; j < QN; ++j) up[j] += gv[t] * sign_floats<QN>(w[t], j);   // shift, and, 2 v_cvt_pk_f32_fp8, 2 v_pk_fma_f32
+          for (int p = 0; p < (QN >= 2 ? QN / 2 : 1); ++p) {      // per group pair: shift, and, 4 packed fp4 converts, 4 v_pk_fma_f32
+            f32x4 ev, od;
+            sign_floats2<QN>(w[t], p, ev, od);
+            up[2 * p] += gv[t] * ev;
+            if (QN >= 2) up[2 * p + 1] += gv[t] * od;
+          }
         }
       };
       uint32_t wA[4], wB[4];

@@ -142,7 +142,7 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void edge_fwd_kernel(const EdgeFwd
       float acc = 0.f;
       SignAcc sg;
 #pragma unroll
-      for (int j = 0; j < QN; ++j) acc = dot4_lrelu_sign(a_r[j], p_r[j], b.q[j], acc, sg);
+      for (int j = 0; j < QN; ++j) acc = dot4_lrelu_sign(a_r[j], p_r[j], b.q[j], acc, sg, j);
       A.sign[k * 64 + lane] = sg.word();                         // one 64-word (256-B) row per edge, coalesced
       e = group_sum<GL>(acc);
     } else if constexpr (ATT == 3) {

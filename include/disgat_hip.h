@@ -49,8 +49,8 @@
  *                       graph bakes drop_seed in, the graph advances this counter itself between replays
  *   sign_bits           att 3 only, optional (NULL = not recorded): uint32 [E | M][64].  Word l of a row belongs
  *                       to lane l = (head h = l / G, g = l % G), G = 64/H, QN = F_out / (4*G); its bit
- *                       8*k + QN-1-j is (P[row] + Q[col] > 0) at feature h*F_out + (j*G+g)*4 + k (k < 4,
- *                       j < QN): which slope leaky_relu took.  disgat_seg_grad_sign computes the score's
+ *                       4*(k + 4*(j&1)) + QH-1-(j>>1), QH = max(1, QN/2), is (P[row] + Q[col] > 0) at feature
+ *                       h*F_out + (j*G+g)*4 + k (k < 4, j < QN): which slope leaky_relu took.  disgat_seg_grad_sign computes the score's
  *                       backward from it without gathering any operand row.
  *   H must be a power of two (the host pads missing heads with zero weights).
  *
