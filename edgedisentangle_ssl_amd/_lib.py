@@ -14,7 +14,8 @@ from concurrent.futures import ThreadPoolExecutor
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libdisgat_hip.so")
-SOURCES = ["api_common.hip", "edge_fwd.hip", "aux_score.hip", "edge_bwd.hip", "gemm_split.hip", "gemm_planes.hip", "optim.hip"]
+SOURCES = ["api_common.hip", "edge_fwd.hip", "aux_score.hip", "edge_bwd.hip", "gemm_split.hip", "gemm_planes.hip", "linear_skinny.hip",
+           "optim.hip"]
 ARCH = "gfx950"
 
 _lib = None
@@ -122,6 +123,8 @@ _SIGS = {
     "disgat_debug_stamps": (_c.c_int, [_P, _c.c_int]),
     "disgat_amax": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _P, _P]),
     "disgat_act_bwd": (_c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int, _c.c_float, _P, _P]),
+    "disgat_linear_skinny": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _c.c_int, _P, _c.c_int64, _P, _c.c_int, _P, _c.c_int64, _P]),
+    "disgat_linear_skinny_wgrad": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _c.c_int, _P, _c.c_int64, _c.c_int, _P, _c.c_int, _P]),
     "disgat_adam_multi": (_c.c_int, [_c.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _c.c_double, _c.c_double, _c.c_float, _P]),
     "disgat_adam_multi_dev": (_c.c_int, [_c.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _c.c_double, _c.c_double, _c.c_float, _P]),
 }

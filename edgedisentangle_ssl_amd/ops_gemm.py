@@ -348,3 +348,45 @@ def linear(a, w, bias=None, init=None, act=ACT_NONE, slope=0.01, a_amax=None, w_
     a_amax: optional precomputed amax(a) (or an upper bound) when the same operand feeds several GEMMs;
     w_split: optional presplit(w) to reuse."""
     return _Linear.apply(a, w, bias, init, act, slope, a_amax, w_split)
+
+
+class _SkinnyLinear(torch.autograd.Function):
+    """x @ w.T + b for a handful of output columns (disgat_linear_skinny); backward = the plain matmuls."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        y = torch.empty((x.shape[0], w.shape[0]), dtype=torch.float32, device=x.device)
+        _lib.call("disgat_linear_skinny", x.data_ptr(), x.stride(0), x.shape[0], x.shape[1], w.data_ptr(), w.stride(0),
+                  0 if b is None else b.data_ptr(), w.shape[0], y.data_ptr(), y.stride(0), ops._stream())
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        gx = g @ w if ctx.needs_input_grad[0] else None
+        gw = None
+        if ctx.needs_input_grad[1]:
+            g = g.contiguous()
+            n_waves = int(min(4096, max(4, (x.shape[0] + 63) // 64 // 4 * 4)))
+            part = torch.empty((n_waves, w.shape[0], x.shape[1]), dtype=torch.float32, device=x.device)
+            _lib.call("disgat_linear_skinny_wgrad", x.data_ptr(), x.stride(0), x.shape[0], x.shape[1], g.data_ptr(), g.stride(0),
+                      w.shape[0], part.data_ptr(), n_waves, ops._stream())
+            gw = part.sum(0)
+        gb = g.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return gx, gw, gb
+
+
+def skinny_ok(x, lin):
+    """A torch.nn.Linear the skinny kernel takes: fp32 device rows of 256 / 512 columns, at most 16 outputs."""
+    w = lin.weight
+    return (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and w.dtype == torch.float32 and w.is_cuda
+            and x.shape[1] in (256, 512) and 0 < w.shape[0] <= 16 and x.stride(1) == 1 and x.stride(0) % 4 == 0
+            and w.stride(1) == 1 and w.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0
+            and (lin.bias is None or lin.bias.is_contiguous()))
+
+
+def skinny_linear(x, lin):
+    """lin(x) for a skinny output layer on disgat_linear_skinny (HBM-bound: one pass over x)."""
+    return _SkinnyLinear.apply(x, lin.weight, lin.bias)

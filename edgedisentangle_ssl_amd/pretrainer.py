@@ -404,7 +404,8 @@ class DifHeadTrainer(Trainer):
                                         mods[1].negative_slope, a_amax=getattr(heads, "fused_amax", None))   # [N, H*hidden]
                 t = t.view(t.shape[0] * nh, -1)
                 for m in mods[2:]:
-                    t = m(t)
+                    # hidden -> nhead logits on N * nhead rows: 1 KB read per 32 B written (ops_gemm.skinny_linear)
+                    t = ops_gemm.skinny_linear(t, m) if isinstance(m, torch.nn.Linear) and ops_gemm.skinny_ok(t, m) else m(t)
                 diag = F.log_softmax(t, dim=1).view(-1, nh, t.shape[1]).diagonal(dim1=1, dim2=2)   # logp[n, i, i]
                 if sharded:
                     loc = -diag.sum() / g.n_global

@@ -278,6 +278,16 @@ int disgat_debug_stamps(unsigned long long* out16, int reset);
 int disgat_act_bwd(const float* g, const float* out, float* gin, int64_t n, int act, float slope,
                    float* amax_out, disgat_stream_t stream);
 
+/* Y[M][N] = X[M][K] W^T + bias for N <= 16 output columns, K = 256 or 512 (W [N][ldw] as nn.Linear keeps it, bias [N] or
+ * NULL): the hidden -> nhead layer at the end of the DifHead classifier (models.py:523-543 on pretrainer.py:819-832's
+ * N_nodes * nhead rows) - 1 KB read per 32 B written, which a GEMM library runs far below the HBM rate.  fp32 FMAs. */
+int disgat_linear_skinny(const float* X, int64_t ldx, int64_t M, int K, const float* W, int64_t ldw,
+                         const float* bias, int N, float* Y, int64_t ldy, disgat_stream_t stream);
+/* Its weight gradient dW[N][K] = G^T X (G [M][N], ldg): every wave of the launch (n_waves, a multiple of 4) writes one
+ * partial [N][K] into partials [n_waves][N][K]; the caller adds them (fixed order: deterministic). */
+int disgat_linear_skinny_wgrad(const float* X, int64_t ldx, int64_t M, int K, const float* G, int64_t ldg, int N,
+                               float* partials, int n_waves, disgat_stream_t stream);
+
 /* ---- optimiser --------------------------------------------------------------------------- */
 
 /* One Adam step for `count` parameter tensors in ONE launch per DISGAT_ADAM_MAX_TENSORS tensors (the table travels in

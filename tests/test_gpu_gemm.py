@@ -207,3 +207,26 @@ def test_weight_gradient_batched_strided_through_autograd():
     refo = torch.nn.functional.elu(torch.bmm(zt.double(), wr).permute(1, 0, 2).reshape(m, H * n))
     (rg,) = torch.autograd.grad((refo * wsum.double()).sum(), [wr])
     assert _err(gw, rg) < 2e-6
+
+
+@pytest.mark.parametrize("m,k,n,bias", [(1000, 256, 8, True), (4097, 512, 4, False), (333, 256, 16, True), (5, 256, 3, True)])
+def test_skinny_linear_matches_fp64(m, k, n, bias):
+    """disgat_linear_skinny (the DifHead classifier's hidden -> nhead layer, models.py:523-543): fp32 FMA result against a
+    float64 product, forward and the gradients of its autograd wrapper."""
+    from edgedisentangle_ssl_amd import ops_gemm
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cpu").manual_seed(m + n)
+    lin = torch.nn.Linear(k, n, bias=bias).to(dev)
+    xbuf = torch.randn(m, k + 4, generator=g).to(dev)                 # a row stride that is not K
+    x = xbuf[:, :k].requires_grad_(True)
+    assert ops_gemm.skinny_ok(x, lin)
+    y = ops_gemm.skinny_linear(x, lin)
+    ref = x.detach().double() @ lin.weight.detach().double().t() + (lin.bias.detach().double() if bias else 0.0)
+    assert float((y.detach().double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+    w = torch.randn(m, n, generator=g).to(dev)
+    (y * w).sum().backward()
+    assert torch.allclose(x.grad, w @ lin.weight.detach(), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(lin.weight.grad, w.t() @ x.detach(), rtol=1e-4, atol=1e-4)
+    if bias:
+        assert torch.allclose(lin.bias.grad, w.sum(0), rtol=1e-5, atol=1e-4)
+    assert not ops_gemm.skinny_ok(x[:, :128], lin) and not ops_gemm.skinny_ok(x.cpu(), lin)
