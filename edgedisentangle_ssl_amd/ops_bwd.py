@@ -181,7 +181,8 @@ def _segments(keys, n_keys, chunk):
     """Work items over a key-sorted list + the int32 permutation that sorts it (None if sorted)."""
     m = keys.numel()
     if m > 1 and not bool((keys[1:] >= keys[:-1]).all()):
-        perm = torch.sort(keys, stable=True).indices
+        # node ids fit 32 bits: the radix sort then runs 4 digit passes instead of 8 (66M column ids: 2.2 -> 1.1 ms)
+        perm = torch.sort(keys.to(torch.int32) if n_keys < 2 ** 31 else keys, stable=True).indices
         keys = keys[perm]
         perm32 = perm.to(torch.int32)
     else:
@@ -202,7 +203,7 @@ def _segments_static(keys, n_keys, is_sorted, chunk):
     if is_sorted:
         perm = perm32 = None
     else:
-        perm = torch.sort(keys, stable=True).indices
+        perm = torch.sort(keys.to(torch.int32) if n_keys < 2 ** 31 else keys, stable=True).indices
         keys = keys[perm]
         perm32 = perm.to(torch.int32)
     ptr = torch.searchsorted(keys, torch.arange(n_keys + 1, device=dev, dtype=keys.dtype))
@@ -336,15 +337,16 @@ def layer_backward_u(ctx, gz, ge, gaux):
             if go is not None and sg is not None]          # [H, M], possibly [M, H]-backed (_g_strides)
     g_a = None
 
-    def dense_side(x_in, w, u, am, need_in, need_w, u_amax):
+    def dense_side(x_in, w, u, am, need_in, need_w, u_amax, add_to=None):
         """(grad x_in, grad w, this side's share of grad a) from u [rows, H*F_out]; u_amax: the bound on |u| the segment
-        passes kept while storing it (max over everything they stored, so >= max |u|), or None."""
+        passes kept while storing it (max over everything they stored, so >= max |u|), or None; add_to: another
+        contribution to grad x_in, added in the GEMM's epilogue."""
         nonlocal g_a
         if u is None:
-            return None, None
+            return add_to, None
         with torch.no_grad():
             g_in, G = ops_gemm.linear_backward(x_in.detach(), (w.detach() * a.detach()) if need_in else w.detach(), u, am,
-                                               need_in, need_w or need_a, g_amax=u_amax)
+                                               need_in, need_w or need_a, g_amax=u_amax, ga_init=add_to if need_in else None)
             g_w = None
             if G is not None:
                 if need_a:
@@ -378,12 +380,22 @@ def layer_backward_u(ctx, gz, ge, gaux):
             sg = None
     ctx.sign = None
     ctx.aux_signs = [None] * len(ctx.aux_signs)
-    g_xq, g_wb = dense_side(x_q, w_bot, u, am_q, need_xq, need_wb, b_col)
+    # x_p, x_q (unsharded: the same tensor) and the aggregation input x (the same again unless it was padded) receive up to
+    # three contributions to ONE gradient: the second GEMM adds the first's result in its epilogue and the aggregation pass
+    # accumulates into that buffer, instead of autograd summing three [N, F_in] tensors afterwards
+    same_pq = x_p is x_q and need_xp and need_xq and g_xp is not None
+    g_xq, g_wb = dense_side(x_q, w_bot, u, am_q, need_xq, need_wb, b_col, add_to=g_xp if same_pq else None)
+    if same_pq:
+        g_xp = None
     u = None
     g_x = None
     if have_edge and need_x:
-        g_x = _keybuf(tuple(x.shape), dev, twi, x.stride(0) != f_in)
-        _seg_hx(1, twi, t.col, t.eid, beta, 0, H, H, f_in, gz.view(n, H * f_in), g_x, False)
+        tgt = g_xq if (x is x_q and g_xq is not None and g_xq.shape == x.shape and g_xq.stride(0) == f_in) else None
+        if tgt is not None and DETERMINISTIC:
+            _seg_hx(1, twi, t.col, t.eid, beta, 0, H, H, f_in, gz.view(n, H * f_in), tgt, True)
+        else:
+            g_x = _keybuf(tuple(x.shape), dev, twi, x.stride(0) != f_in)
+            _seg_hx(1, twi, t.col, t.eid, beta, 0, H, H, f_in, gz.view(n, H * f_in), g_x, False)
     return (g_x, None, None, g_a if need_a else None, None) + (None,) * n_lists + (g_xp, g_wt, g_xq, g_wb)
 
 

@@ -276,15 +276,16 @@ def _weight_grad(a, g, a_amax, g_amax):
     return out if batched else out[0]
 
 
-def linear_backward(a, w, g, a_amax=None, need_a=True, need_w=True, g_amax=None):
+def linear_backward(a, w, g, a_amax=None, need_a=True, need_w=True, g_amax=None, ga_init=None):
     """(grad a, grad w) of a @ w (2-D, no bias / activation) on the f16x3 kernels where their tiling allows.
-    g_amax: max |g| (or an upper bound) as a device scalar when the producer of g measured it already."""
+    g_amax: max |g| (or an upper bound) as a device scalar when the producer of g measured it already;
+    ga_init: a tensor of grad a's shape added in the GEMM epilogue (another contribution to the same gradient)."""
     g_am = None
     if mode() == "f16x3" and g.is_cuda and g.dim() == 2 and g.is_contiguous() and g.shape[1] % 4 == 0 and g.data_ptr() % 16 == 0:
         g_am = g_amax if g_amax is not None else amax(g)
     ga = gw = None
     if need_a:
-        ga = _forward(g, w.t(), None, None, ACT_NONE, 0.0, g_am)
+        ga = _forward(g, w.t(), None, ga_init, ACT_NONE, 0.0, g_am)
     if need_w:
         if g_am is not None and _tn_ok(a, g, a.shape[1], g.shape[1]):
             gw = _weight_grad(a, g, a_amax if a_amax is not None else amax(a), g_am)
