@@ -369,9 +369,15 @@ def secondary_measurements(o, enc, trainers, graph, x, lists):
             tr._finish_step(fn(), graph)
     try:
         torch.cuda.reset_peak_memory_stats()
-        out["train_step_ms"] = round(timed(train, 2), 3)
+        out["train_step_ms"] = round(timed(train, 3), 3)
         out["train_step_peak_GiB"] = round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)
         out["train_step_def"] = "SupEdge + DisEdge + DifHead: forward + backward + multi-tensor Adam, attention dropout 0.1"
+        prev = enc.skip_unused
+        enc.skip_unused = True          # as main.run trains: the layer-2 aggregation + fuser that SupEdge / DisEdge discard is skipped
+        try:
+            out["train_step_skip_unused_ms"] = round(timed(train, 2), 3)
+        finally:
+            enc.skip_unused = prev
     except torch.OutOfMemoryError as exc:          # report, never fail the headline over a secondary number
         out["train_step_ms"] = None
         out["train_step_error"] = str(exc)[:200]
