@@ -132,9 +132,10 @@ class StaticStep:
         for o in self.trainer.models_opt:
             o.zero_grad()
         torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.logs = self._body(*args)
+        graph = torch.cuda.CUDAGraph()          # (a capture the stream refuses - a host read inside the step, say - raises here;
+        with torch.cuda.graph(graph):           #  on this ROCm the process does not recover from that: fix the step or run
+            self.logs = self._body(*args)       #  with --capture off)
+        self.graph = graph
         self._restore(snap)             # the host generator again: the first replay draws what an uncaptured first step would
 
     def __call__(self, *args):

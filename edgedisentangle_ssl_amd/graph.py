@@ -113,6 +113,8 @@ class CSRGraph:
         if self._pairs is None:
             self._pairs = self.indices().contiguous()
             self._pairs._disgat_checked = (int(self.n), int(getattr(self, "n_cols", self.n)), self._pairs._version)
+            self._pairs._disgat_static = True      # backward segment tables without host round trips (ops_bwd._segments_static):
+                                                   # the list is a fixed part of the graph, also inside captured steps
         return self._pairs
 
     # ------------------------------------------------------------------ work items
