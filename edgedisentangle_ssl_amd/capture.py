@@ -9,6 +9,25 @@ fixed between replays; inputs are updated in place through the static tensors.
 import torch
 
 
+class _no_gc:
+    """No cyclic garbage collection while a stream is capturing.  A collection that happens to run inside the capture
+    can finalise objects of EARLIER work - a HIP graph, events, a trainer with its StaticStep (they form a reference
+    cycle, so only the cyclic collector frees them) - and destroying those is not permitted during capture: the process
+    aborts inside the destructor.  torch.cuda.graph() collects once on entry; this keeps the collector off until exit."""
+
+    def __enter__(self):
+        import gc
+        gc.collect()
+        self.was = gc.isenabled()
+        gc.disable()
+
+    def __exit__(self, *exc):
+        import gc
+        if self.was:
+            gc.enable()
+        return False
+
+
 class CapturedCall:
     """`fn(*static_inputs)` captured into one HIP graph.  call(*new_inputs) copies the new values
     into the static input buffers, replays, and returns the (static) outputs."""
@@ -22,7 +41,7 @@ class CapturedCall:
                 fn(*static_inputs)
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(self.graph):
+        with torch.no_grad(), _no_gc(), torch.cuda.graph(self.graph):
             self.outputs = fn(*static_inputs)
 
     def __call__(self, *inputs):
@@ -133,8 +152,8 @@ class StaticStep:
             o.zero_grad()
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()          # (a capture the stream refuses - a host read inside the step, say - raises here;
-        with torch.cuda.graph(graph):           #  on this ROCm the process does not recover from that: fix the step or run
-            self.logs = self._body(*args)       #  with --capture off)
+        with _no_gc(), torch.cuda.graph(graph):     # on this ROCm the process does not recover from that: fix the step or
+            self.logs = self._body(*args)           # run with --capture off)
         self.graph = graph
         self._restore(snap)             # the host generator again: the first replay draws what an uncaptured first step would
 
