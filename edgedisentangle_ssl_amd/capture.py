@@ -70,14 +70,16 @@ def capture_get_em(encoder, x, adj, fusers):
 #   * backward segment structures built without reading sizes back (ops_bwd._segments_static);
 #   * attention-dropout seeds = a per-call-site constant + a device counter the step advances (layers.StepSeed);
 #   * Adam's step counts on the device (optim.DeviceStepAdam / disgat_adam_multi_dev).
-# The first call runs the step eagerly a few times to build every cache (CSR transpose, work items, hipBLASLt
+# The first call runs the step eagerly once to build every cache (CSR transpose, work items, hipBLASLt
 # workspaces), ROLLS the trainer BACK to where it started (parameters, Adam moments and counts, seed counter, RNG
 # streams), captures, and from then on replays - so step 1 of the run already comes from the graph and a captured
 # run follows the same trajectory as the same static step run eagerly (tests/test_gpu_capture.py).
 class StaticStep:
-    def __init__(self, trainer, host_fn, device_fn, warmup=2):
+    def __init__(self, trainer, host_fn, device_fn, warmup=1):
         from . import layers, optim
-        self.trainer, self.host_fn, self.device_fn, self.warmup = trainer, host_fn, device_fn, warmup
+        import os
+        self.trainer, self.host_fn, self.device_fn = trainer, host_fn, device_fn
+        self.warmup = int(os.environ.get("DISGAT_CAPTURE_WARMUP", warmup))
         dev = next(trainer.models[0].parameters()).device
         self.seed = layers.StepSeed(dev)
         self.adam = optim.DeviceStepAdam(trainer.models_opt)
