@@ -229,7 +229,7 @@ def _pack_score_operands(layers, x, x_all, att, H, Hp, f_in, f_out, fp, am=None,
             wst = torch.stack([l.W for l in layers])                                     # [H, 2 F_in, F_out]
             wt = wst[:, :f_in].permute(1, 0, 2).reshape(f_in, H * f_out)
             wb = wst[:, f_in:].permute(1, 0, 2).reshape(f_in, H * f_out)
-            a_vec = torch.stack([l.a[:, 0] for l in layers]).reshape(-1)
+            a_vec = torch.stack([l.a for l in layers]).reshape(-1)       # [H, F_out, 1] -> flat: no per-head select in the graph
             return wt, wb, a_vec, ops_gemm.presplit(wt), ops_gemm.presplit(wb)
         tops = [F.pad(l.W[:f_in, c0:c1], (0, fp - fw)) for l in layers] + [x.new_zeros(f_in, fp)] * (Hp - H)
         bots = [F.pad(l.W[f_in:, c0:c1], (0, fp - fw)) for l in layers] + [x.new_zeros(f_in, fp)] * (Hp - H)
