@@ -398,7 +398,7 @@ def small_graph_epochs():
     """Wall time per epoch of the reference's whole training flow (main.py:270-360: 5 CLS steps + SupEdge + DisEdge +
     DifHead train_steps, H = 8, nhid 64, att 3, dropout 0.1, Adam) on the bundled real graphs of BASELINE configs[1],
     through edgedisentangle_ssl_amd.main.run - host-bound territory.  main.run replays every train_step
-    from a HIP graph there (--capture auto); reported per graph:
+    from a HIP graph there (--capture on; `auto` does the same from 24 epochs up); reported per graph:
       the steady-state epoch = (a 68-epoch run - an 8-epoch run) / 60, both complete main.run calls (data load, model
       build, warm-up + capture of the four step graphs included in each, so they cancel),
       `first_8_epochs_ms_per_epoch` = the 8-epoch run / 8 (what a very short run pays per epoch, capture included),
@@ -423,7 +423,7 @@ def small_graph_epochs():
 
         try:
             drop_in.run(argv + ["--epochs", "2"])          # warm-up: library load, hipBLASLt heuristics
-            t8, t68 = timed(8, "auto"), timed(68, "auto")
+            t8, t68 = timed(8, "on"), timed(68, "on")
             res[name] = round((t68 - t8) / 60, 1)
             e8, e38 = timed(8, "off"), timed(38, "off")
             detail[name] = {"first_8_epochs_ms_per_epoch": round(t8 / 8, 1), "eager_ms_per_epoch": round((e38 - e8) / 30, 1)}

@@ -18,6 +18,7 @@ from .graph import graph_of
 from .utils import get_parser, resolve_logs
 
 CAPTURE_MAX_EDGES = 2_000_000     # --capture auto: above this a step is kernel-bound and the eager path's load balancing matters
+CAPTURE_MIN_EPOCHS = 24           # --capture auto: capturing costs 0.3-0.5 s once; at ~20 ms saved per epoch shorter runs stay eager
 
 SSL = {"DisEdge": pretrainer.GeneratedEdgeTrainer, "SupEdge": pretrainer.SupEdgeTrainer, "DifHead": pretrainer.DifHeadTrainer}
 
@@ -65,8 +66,9 @@ def run(argv=None, log=print):
     parser.add_argument("--fixture", type=str, default=None)
     parser.add_argument("--quiet", action="store_true", default=False)
     parser.add_argument("--capture", choices=("auto", "on", "off"), default="auto",
-                        help="replay every train_step from a HIP graph (capture.StaticStep); auto = one process and a graph "
-                             "of at most CAPTURE_MAX_EDGES edges, where a step is launch-bound")
+                        help="replay every train_step from a HIP graph (capture.StaticStep); auto = one process, a graph of at "
+                             "most CAPTURE_MAX_EDGES edges (where a step is launch-bound) and at least CAPTURE_MIN_EPOCHS epochs "
+                             "(capturing costs 0.3-0.5 s once per run)")
     args = parser.parse_args(argv)
     if args.model != "DISGAT":
         raise SystemExit("only --model=DISGAT is implemented by this package (SURVEY 2: other encoders out of scope)")
@@ -151,7 +153,7 @@ def run(argv=None, log=print):
 
     if world > 1:
         reseed_rank(args.seed, rank)
-    captured = args.capture == "on" or (args.capture == "auto" and world == 1
+    captured = args.capture == "on" or (args.capture == "auto" and world == 1 and args.epochs >= CAPTURE_MIN_EPOCHS
                                         and all(graph_of(a).nnz <= CAPTURE_MAX_EDGES for a in adjs))
     if captured and world > 1:
         raise SystemExit("--capture on: captured steps run on one process (the sharded step holds collectives)")
