@@ -67,3 +67,55 @@ def test_multi_adam_many_tensors_and_state_dict():
     cpu.grad = torch.ones(4)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         optim.ModuleAdam([cpu]).step()
+
+
+def test_device_step_adam_equals_the_host_step_form():
+    """optim.DeviceStepAdam (disgat_adam_multi_dev: step counts in device memory, bias corrections formed in the kernel -
+    what a train_step captured in a HIP graph replays) against optim.step_all on the same gradients: identical
+    parameters and moments, host step counts kept in step, a re-sync after host-side steps in between."""
+    from edgedisentangle_ssl_amd import optim
+    dev = torch.device("cuda:0")
+    a, b = _mods(dev, 5), _mods(dev, 5)
+    cuts = [(0, 4), (4, 9)]
+    oa = [optim.ModuleAdam(a[i:j], lr=0.01, weight_decay=5e-4) for i, j in cuts]
+    ob = [optim.ModuleAdam(b[i:j], lr=0.01, weight_decay=5e-4) for i, j in cuts]
+    dsa = optim.DeviceStepAdam(ob)
+    g = torch.Generator(device=dev).manual_seed(2)
+
+    def grads():
+        for p, q in zip(a, b):
+            gr = torch.randn(p.shape, device=dev, generator=g)
+            p.grad, q.grad = gr.clone(), gr.clone()
+
+    for it in range(12):
+        grads()
+        optim.step_all(oa)
+        if it == 6:                       # a host-side step in between (an eager train_step): the device counts re-sync
+            optim.step_all(ob)
+        else:
+            dsa.sync()
+            dsa.step()
+            dsa.advance_host()
+    for k, (p, q) in enumerate(zip(a, b)):
+        assert torch.equal(p, q), (k, float((p - q).abs().max()))
+    for o1, o2 in zip(oa, ob):
+        for p, q in zip(o1.params, o2.params):
+            s1, s2 = o1.state[id(p)], o2.state[id(q)]
+            assert s1[0] == s2[0] == 12 and torch.equal(s1[1], s2[1]) and torch.equal(s1[2], s2[2])
+    assert dsa.steps.tolist() == [12] * len(b)
+    # the set of parameters with a gradient must not change under a captured step
+    b[0].grad = None
+    with pytest.raises(RuntimeError, match="changed"):
+        dsa.step()
+
+
+def test_skinny_linear_rejects_shapes_it_does_not_tile():
+    from edgedisentangle_ssl_amd import _lib
+    x = torch.zeros(8, 256, device="cuda")
+    w = torch.zeros(8, 256, device="cuda")
+    y = torch.zeros(8, 8, device="cuda")
+    for k, n in ((128, 8), (256, 17), (256, 0)):
+        with pytest.raises(RuntimeError):
+            _lib.call("disgat_linear_skinny", x.data_ptr(), 256, 8, k, w.data_ptr(), 256, 0, n, y.data_ptr(), 8, 0)
+    with pytest.raises(RuntimeError):
+        _lib.call("disgat_linear_skinny_wgrad", x.data_ptr(), 256, 8, 256, y.data_ptr(), 8, 8, w.data_ptr(), 6, 0)   # n_waves % 4
