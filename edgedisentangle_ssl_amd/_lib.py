@@ -17,6 +17,8 @@ LIB_PATH = os.path.join(_HERE, "libdisgat_hip.so")
 SOURCES = ["api_common.hip", "edge_fwd.hip", "aux_score.hip", "edge_bwd.hip", "gemm_split.hip", "gemm_planes.hip", "linear_skinny.hip",
            "optim.hip"]
 ARCH = "gfx950"
+ABI_VERSION = 3         # csrc/api_common.hip: bumped whenever a launcher's argument list changes (round 3: dropout seed
+                        # counter, padding labels / items, score-gradient strides, amax outputs, plane outputs)
 
 _lib = None
 
@@ -143,6 +145,15 @@ def load():
     if _stale():
         build()
     lib = ctypes.CDLL(LIB_PATH)
+    lib.disgat_abi_version.restype = _c.c_int
+    if lib.disgat_abi_version() != ABI_VERSION:
+        # a library built from other sources than the signatures below describe (a stale in-tree .so whose timestamps look
+        # fresh): calling it would pass arguments in the wrong slots - rebuild once, then refuse
+        build(force=True)
+        lib = ctypes.CDLL(LIB_PATH)
+        lib.disgat_abi_version.restype = _c.c_int
+        if lib.disgat_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"libdisgat_hip.so reports ABI {lib.disgat_abi_version()}, this package binds ABI {ABI_VERSION}")
     for name, (res, args) in _SIGS.items():
         try:
             fn = getattr(lib, name)

@@ -76,7 +76,7 @@ extern "C" {
 
 typedef void* disgat_stream_t; /* hipStream_t */
 
-int disgat_abi_version(void);
+int disgat_abi_version(void);          /* 3 in this revision; changes with any launcher's argument list */
 const char* disgat_last_error(void);
 
 /* Fused score -> sigmoid -> row softmax -> aggregation for all H heads of one layer.

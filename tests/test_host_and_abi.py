@@ -22,7 +22,8 @@ def test_library_builds_loads_and_exports_header_symbols():
         assert hasattr(lib, sym), f"{sym} declared in include/disgat_hip.h but not exported"
     assert declared == _lib.exported_symbols(), (declared, _lib.exported_symbols())
     lib.disgat_abi_version.restype = ctypes.c_int
-    assert lib.disgat_abi_version() >= 1
+    from edgedisentangle_ssl_amd import _lib as binding
+    assert lib.disgat_abi_version() == binding.ABI_VERSION      # the loader rebuilds / refuses a library of another ABI
 
 
 def test_csr_and_work_items_cover_every_edge_once():
