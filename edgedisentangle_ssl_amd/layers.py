@@ -323,7 +323,17 @@ class StepSeed:
 STEP_SEED = None       # set by capture.StaticStep around a step's forward + backward
 
 
-def disga_heads(layers, x, adj, aux_indices=None, head_ranges=None, aux_only=False, heads_planes=False):
+def disga_heads(layers, x, adj, aux_indices=None, head_ranges=None, aux_only=False, heads_planes=False, heads_discarded=False):
+    """All heads of one layer in fused passes: see _disga_heads (this wrapper only restores the autograd mode, which the
+    implementation switches off for the tail of a layer whose per-head outputs the caller discards)."""
+    prev = torch.is_grad_enabled()
+    try:
+        return _disga_heads(layers, x, adj, aux_indices, head_ranges, aux_only, heads_planes, heads_discarded)
+    finally:
+        torch.set_grad_enabled(prev)
+
+
+def _disga_heads(layers, x, adj, aux_indices=None, head_ranges=None, aux_only=False, heads_planes=False, heads_discarded=False):
     """All H heads of one DISGAT layer: the loop of models.py:225-228 as ONE fused edge pass.
 
     layers: the H DisGALayer modules (parameter holders).  adj: torch sparse COO or CSRGraph.
@@ -331,10 +341,15 @@ def disga_heads(layers, x, adj, aux_indices=None, head_ranges=None, aux_only=Fal
     optional list of (lo,hi) per aux list restricting which heads are scored on it (DisEdge uses
     half the heads per list, pretrainer.py:619-620); unscored heads' entries are None.
     aux_only: score the aux pairs only (no edge pass, no aggregation): returns (None, None, aux).
+    heads_discarded: the caller computes this layer's aggregation / per-head outputs / edge scores only because the
+    reference does and then drops them (predict_adjs_sparse's second layer, models.py:319-330): with autograd on, the
+    fused layer pass then records no sign words for the edge list and everything after it runs without a graph - no
+    gradient can reach those values, the aux scores keep theirs.
     heads_planes: the caller's consumer of the heads takes ops_gemm.Planes (our FuseLayer, the DifHead classifier): on
     a no-graph forward the head buffer is then written ONLY as planes (HeadList.planes; the list itself stays empty).
     Returns (HeadList of elu(h') [N,F_out], [edge_e[E,1]]*H, [[aux_e[M_l,1]]_l]*H or None).
     """
+    grad_mode = torch.is_grad_enabled()
     l0 = layers[0]
     att, gnn = l0.att_type, l0.gnn_type
     H = len(layers)
@@ -446,15 +461,18 @@ def disga_heads(layers, x, adj, aux_indices=None, head_ranges=None, aux_only=Fal
                 ranges = tuple((0, H) if head_ranges is None or head_ranges[li] is None else tuple(head_ranges[li])
                                for li in range(len(lists)))
                 cfg = (graph, att, Hk, f_in_p, fp, gnn == "SAGE", d, ranges)
+                detach_edge = bool(heads_discarded and aux_indices)          # edge list: values only (see heads_discarded)
                 if own:
                     # the pass owns P = x W_top and Q = x_all W_bot: their values go in detached, nothing of them is kept
                     # for the backward, which returns gradients for the GEMMs' inputs instead (ops_bwd.layer_backward_u)
                     (x_p, w_top, am_p, _s1), (x_q, w_bot, am_q, _s2) = recipes
-                    z, edge_e, _den, *maux = ops.LayerPass.apply(xg, r.detach(), c.detach(), av, cfg + ((am_p, am_q),), *lists,
-                                                                 x_p, w_top, x_q, w_bot)
+                    z, edge_e, _den, *maux = ops.LayerPass.apply(xg, r.detach(), c.detach(), av, cfg + ((am_p, am_q), detach_edge),
+                                                                 *lists, x_p, w_top, x_q, w_bot)
                 else:
-                    z, edge_e, _den, *maux = ops.LayerPass.apply(xg, r, c, av, cfg, *lists)
+                    z, edge_e, _den, *maux = ops.LayerPass.apply(xg, r, c, av, cfg + (None, detach_edge), *lists)
                 merged_aux = maux if aux_indices else None
+                if detach_edge:
+                    torch.set_grad_enabled(False)        # projection / fuser input of discarded heads: no graph (restored by the wrapper)
             elif use_pl:
                 # no-graph forward: the aggregate leaves the edge pass as the two fp16 planes the projection GEMM consumes
                 z, edge_e, _den = ops.edge_forward(graph, att, Hk, f_in_p, fp, xg, r, c, av, gnn == "SAGE", d, need_den=False,
@@ -552,6 +570,7 @@ def disga_heads(layers, x, adj, aux_indices=None, head_ranges=None, aux_only=Fal
             heads.pre_elu = None if concat else [fused[:, h * f_out:(h + 1) * f_out] for h in range(H)]
             e_list = [edge_e[h].unsqueeze(1) for h in range(H)]
 
+    torch.set_grad_enabled(grad_mode)           # the aux scores below stay in the graph (heads_discarded only covers the tail above)
     aux_out = None
     if aux_indices is not None:
         per_list = []

@@ -268,14 +268,16 @@ class LayerPass(torch.autograd.Function):
     cfg are the aux lists.  With a ninth cfg entry (am_p, am_q) the node also OWNS the GEMMs behind P and Q: four more
     tensors follow the lists - x_p, W_top, x_q, W_bot with rowop = x_p W_top, colop = x_q W_bot - rowop / colop are taken
     as plain values (detached), nothing of them is saved, and the backward hands gradients to those four instead
-    (ops_bwd.layer_backward_u: no operand table is read or rebuilt)."""
+    (ops_bwd.layer_backward_u: no operand table is read or rebuilt).  A tenth entry True detaches the edge list: its outputs
+    are plain values (no sign record, non-differentiable) - layers.disga_heads(heads_discarded=True)."""
 
     @staticmethod
     def forward(ctx, x, rowop, colop, a, cfg, *rest):
         graph, att, H, F_in, F_out, sage, drop, ranges = cfg[:8]
         ctx.u_am = cfg[8] if len(cfg) > 8 else None
+        edge_detached = len(cfg) > 9 and bool(cfg[9])     # the edge list's outputs are plain values: no sign record, no gradient
         lists = rest[:len(ranges)]
-        ctx.sign = sign_record(att, H, F_out, graph.nnz, x.device) if graph.nnz else None
+        ctx.sign = sign_record(att, H, F_out, graph.nnz, x.device) if (graph.nnz and not edge_detached) else None
         z, edge_e, den = edge_forward(graph, att, H, F_in, F_out, x, rowop, colop, a, sage, drop, sign=ctx.sign)
         outs, ctx.aux_signs = [], []
         for pairs, (lo, hi) in zip(lists, ranges):
@@ -288,7 +290,10 @@ class LayerPass(torch.autograd.Function):
             ctx.save_for_backward(x, a, z, edge_e, den, *lists, *rest[len(ranges):])
         else:
             ctx.save_for_backward(x, rowop, colop, a, z, edge_e, den, *lists)
-        ctx.mark_non_differentiable(den)
+        if edge_detached:
+            ctx.mark_non_differentiable(z, edge_e, den)
+        else:
+            ctx.mark_non_differentiable(den)
         ctx.set_materialize_grads(False)      # outputs nobody differentiates arrive as None, and their passes are skipped
         return (z, edge_e, den, *outs)
 
