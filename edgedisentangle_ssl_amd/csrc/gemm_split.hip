@@ -698,8 +698,23 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_tn_kernel(const GemmTNArgs 
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int nt = T.N / 128;
-  const int ka0 = (blockIdx.x / nt) * 128, n0 = (blockIdx.x % nt) * 128;
-  const int sp = blockIdx.y, bz = blockIdx.z;
+  // XCD-aware block -> (tile, split) map.  All tiles of one split read the same row range of both operands; workgroups go
+  // to the 8 XCDs round-robin in launch order, so with the plain map the 32 tiles of a split sat on 8 different L2s and
+  // each fetched its own copy: 23.7 GB through the fabric per launch for 9 GB of operands.  Here XCD c takes whole splits
+  // c, c + 8, ...: 13.6 GB (rocprofv3 --pmc FETCH_SIZE, tools/wgrad_bench.py).  The time moves by 2-5 % only - the kernel
+  // is bound by its own split + LDS + MFMA phases, not by the fabric - but half the traffic is half the traffic.
+  int tile = blockIdx.x, sp = blockIdx.y;
+  {
+    const int nx = gridDim.x, S = gridDim.y;
+    if ((S & 7) == 0) {
+      const int L = blockIdx.x + nx * blockIdx.y;      // launch order within this batch slab (nx * S is a multiple of 8)
+      const int q = L >> 3;
+      tile = q % nx;
+      sp = (q / nx) * 8 + (L & 7);
+    }
+  }
+  const int ka0 = (tile / nt) * 128, n0 = (tile % nt) * 128;
+  const int bz = blockIdx.z;
   const int k_begin = sp * T.rows_per_split;
   const int k_end = min(T.M, k_begin + T.rows_per_split);
 

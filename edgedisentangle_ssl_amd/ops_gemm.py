@@ -268,6 +268,8 @@ def _weight_grad(a, g, a_amax, g_amax):
     n = g.shape[-1]
     tiles = (k // 128) * (n // 128) * hb
     splits = max(1, min(64, -(-1024 // tiles), m // 2048))
+    if splits >= 8:
+        splits -= splits % 8        # whole splits per XCD (the kernel's block map keeps a split's tiles on one L2)
     part = torch.empty((hb, splits, k, n), dtype=torch.float32, device=a.device)
     _lib.call("disgat_gemm_f16x3_tn", a.data_ptr(), a.stride(-2), a.stride(0) if batched else 0, g.data_ptr(), g.stride(-2),
               g.stride(0) if batched else 0, a_amax.data_ptr(), g_amax.data_ptr(), part.data_ptr(), m, k, n, hb, splits,
