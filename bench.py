@@ -378,6 +378,22 @@ def secondary_measurements(o, enc, trainers, graph, x, lists):
             out["train_step_skip_unused_ms"] = round(timed(train, 2), 3)
         finally:
             enc.skip_unused = prev
+        # the trainers' own train_step()s: every step draws its pair lists with the sampler kernels (csrc/pair_sample.hip:
+        # Bernoulli(3 rho) over all N^2 entries + a third of the positives, as pretrainer.py:683-707, 524-576), then forward +
+        # backward + Adam as above.  List sizes follow the graph (SupEdge ~ 10/3 nnz, DisEdge by the label split).
+        from edgedisentangle_ssl_amd import synth
+        dis.get_label_all(x, graph, synth.node_labels(graph.n, x.device))
+
+        def train_sampled():
+            sup.train_step(data, graph)
+            dis.train_step(data)
+            dif.train_step(data)
+        out["train_step_with_sampling_ms"] = round(timed(train_sampled, 2), 3)
+        smp = sup.samplers(data, graph)[0]
+        med, _lo, _hi = median_of(smp.sample, 7, 1)
+        out["sampler_ms_per_list"] = round(med, 3)
+        out["sampler_def"] = (f"one SupEdge list ({int(smp.meta[3])} pairs of {graph.n}^2 entries): count + scan + emit kernels and the "
+                              "length read-back; train_step_with_sampling_ms = the three trainers' train_step() incl. their 3 lists")
     except torch.OutOfMemoryError as exc:          # report, never fail the headline over a secondary number
         out["train_step_ms"] = None
         out["train_step_error"] = str(exc)[:200]

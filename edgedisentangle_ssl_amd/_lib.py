@@ -15,10 +15,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libdisgat_hip.so")
 SOURCES = ["api_common.hip", "edge_fwd.hip", "aux_score.hip", "edge_bwd.hip", "gemm_split.hip", "gemm_planes.hip", "linear_skinny.hip",
-           "optim.hip"]
+           "optim.hip", "pair_sample.hip"]
 ARCH = "gfx950"
-ABI_VERSION = 3         # csrc/api_common.hip: bumped whenever a launcher's argument list changes (round 3: dropout seed
-                        # counter, padding labels / items, score-gradient strides, amax outputs, plane outputs)
+ABI_VERSION = 4         # csrc/api_common.hip: bumped whenever a launcher's argument list changes (round 3: dropout seed
+                        # counter, padding labels / items, score-gradient strides, amax outputs, plane outputs; round 4: pair sampler)
 
 _lib = None
 
@@ -127,6 +127,10 @@ _SIGS = {
     "disgat_act_bwd": (_c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int, _c.c_float, _P, _P]),
     "disgat_linear_skinny": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _c.c_int, _P, _c.c_int64, _P, _c.c_int, _P, _c.c_int64, _P]),
     "disgat_linear_skinny_wgrad": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _c.c_int, _P, _c.c_int64, _c.c_int, _P, _c.c_int, _P]),
+    "disgat_pair_sample_plan": (_c.c_int, [_P, _c.c_int, _c.c_int, _P, _c.c_int64, _c.c_int64, _c.c_double, _c.c_int64, _P, _P, _P, _P,
+                                           _P, _P]),
+    "disgat_pair_sample_emit": (_c.c_int, [_P, _c.c_int, _c.c_int, _P, _c.c_int64, _c.c_int64, _c.c_double, _c.c_int64, _c.c_int64,
+                                           _c.c_int64, _P, _P, _P, _P, _P, _c.c_int, _P]),
     "disgat_adam_multi": (_c.c_int, [_c.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _c.c_double, _c.c_double, _c.c_float, _P]),
     "disgat_adam_multi_dev": (_c.c_int, [_c.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _c.c_double, _c.c_double, _c.c_float, _P]),
 }

@@ -75,10 +75,18 @@ def capture_get_em(encoder, x, adj, fusers):
 # streams), captures, and from then on replays - so step 1 of the run already comes from the graph and a captured
 # run follows the same trajectory as the same static step run eagerly (tests/test_gpu_capture.py).
 class StaticStep:
+    """Owned by its trainer (Trainer.static_step keeps it); holds the trainer only WEAKLY and takes the trainer's step
+    functions unbound, so trainer and step form no reference cycle: dropping the trainer (or Trainer.close()) frees the step
+    and its HIP graph right there, by reference count - not whenever the cyclic collector next runs, which may be in the middle
+    of somebody else's stream capture, where destroying a graph aborts the process."""
+
     def __init__(self, trainer, host_fn, device_fn, warmup=1):
         from . import layers, optim
         import os
-        self.trainer, self.host_fn, self.device_fn = trainer, host_fn, device_fn
+        import weakref
+        self._trainer = weakref.ref(trainer)
+        self._host_fn = getattr(host_fn, "__func__", host_fn)          # unbound: a bound method would hold the trainer
+        self._device_fn = getattr(device_fn, "__func__", device_fn)
         self.warmup = int(os.environ.get("DISGAT_CAPTURE_WARMUP", warmup))
         dev = next(trainer.models[0].parameters()).device
         self.seed = layers.StepSeed(dev)
@@ -86,6 +94,31 @@ class StaticStep:
         self.graph = None
         self.logs = None
         self.replays = 0
+
+    @property
+    def trainer(self):
+        tr = self._trainer()
+        if tr is None:
+            raise RuntimeError("StaticStep: its trainer is gone")
+        return tr
+
+    def host_fn(self, *args):
+        """Host half of a step: the trainer's own (nothing, today) + the pair samplers' seeds.  A sampler takes its seed from
+        torch's CPU generator at first use - a device fill that must not end up inside the graph (every replay would reset
+        the generator's step with it)."""
+        tr = self.trainer
+        self._host_fn(tr, *args)
+        for smp in tr.samplers(*args):
+            if hasattr(smp, "_ensure_seed"):
+                smp._ensure_seed()
+
+    def device_fn(self, adam, *args):
+        return self._device_fn(self.trainer, adam, *args)
+
+    def close(self):
+        """Free the HIP graph now."""
+        self.graph = None
+        self.logs = None
 
     # -- one execution of the step's device half (eager or under capture)
     def _body(self, *args):
@@ -107,14 +140,15 @@ class StaticStep:
         self.adam.advance_host()
         return logs
 
-    def _snapshot(self):
+    def _snapshot(self, *args):
         tr = self.trainer
+        samplers = [(smp, smp._seeded, smp.meta.clone()) for smp in tr.samplers(*args) if hasattr(smp, "meta")]
         params = [p for m in tr.models for p in m.parameters()]
         opt = []
         for o in tr.models_opt:
             opt.append({id(p): (st[0], st[1].clone(), st[2].clone()) for p in o.params for st in [o.state.get(id(p))] if st is not None})
         return dict(params=[(p, p.detach().clone()) for p in params], opt=opt, seed=self.seed.counter.clone(),
-                    cpu_rng=torch.get_rng_state(), cuda_rng=torch.cuda.get_rng_state())
+                    cpu_rng=torch.get_rng_state(), cuda_rng=torch.cuda.get_rng_state(), samplers=samplers)
 
     def _restore(self, snap):
         tr = self.trainer
@@ -136,11 +170,14 @@ class StaticStep:
                         st[1].copy_(old[1])
                         st[2].copy_(old[2])
             self.seed.counter.copy_(snap["seed"])
+            for smp, seeded, meta in snap["samplers"]:      # generator (seed, step) and event counters back; an unseeded sampler
+                smp.meta.copy_(meta)                        # draws its seed again, from the restored CPU generator
+                smp._seeded = seeded
         torch.set_rng_state(snap["cpu_rng"])
         torch.cuda.set_rng_state(snap["cuda_rng"])
 
     def _capture(self, *args):
-        snap = self._snapshot()
+        snap = self._snapshot(*args)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):

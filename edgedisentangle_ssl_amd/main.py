@@ -188,7 +188,21 @@ def run(argv=None, log=print):
                 log_ep.update(tr.train_step_captured(data_of.setdefault(id(a), [features, a]), ssl_labels[i]))
             else:
                 log_ep.update(tr.train_step([features, a], ssl_labels[i]))
+        # the pair samplers' event counters (sampling.PairSampler: an item over a kernel capacity / a fixed-capacity list that
+        # came out longer than its 8-sigma capacity and was cut) travel with the step logs; a run that trained on a cut list says so
+        events = [smp.meta[4:6] for i, tr in enumerate(ssl_trainers) for smp in
+                  tr.samplers([features, adjs[args.pre_edge[i] - 1]], ssl_labels[i]) if hasattr(smp, "meta")]
+        if events:
+            ev = torch.stack(events).sum(0)
+            log_ep["sampler_overflow"], log_ep["sampler_clamped"] = ev[0], ev[1]
         log_ep = resolve_logs(log_ep)                    # the step logs are device scalars: one transfer per epoch
+        if events:
+            bad = (int(log_ep.pop("sampler_overflow")), int(log_ep.pop("sampler_clamped")))
+            if bad != (0, 0):
+                msg = "pair sampler: {} item(s) over a kernel capacity, {} list(s) cut at the fixed capacity".format(*bad)
+                if captured:
+                    raise RuntimeError(msg + " (--capture on trains on fixed-capacity lists; rerun with --capture off)")
+                log_ep["sampler_events"] = msg
         history.append(log_ep)
         if not args.quiet:
             log(" ".join("{}={:.5g}".format(k, v) if isinstance(v, float) else "{}={}".format(k, v) for k, v in log_ep.items()))

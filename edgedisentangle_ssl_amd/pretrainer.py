@@ -37,9 +37,18 @@ def _global_count(t, graph):
     return int(parallel.all_reduce_sum(c, graph))
 
 
-def _sample(graph, pos, n_pos_global):
-    """Pairs over this process's rows (sampling.py): local row ids, global column ids."""
-    return sampling.sample_pairs(graph.n, pos, n_cols=graph.n_cols, n_pos_global=n_pos_global)
+def _sampler(graph, pos, n_pos_global=None):
+    """The pair sampler of one positive set over this process's rows (sampling.PairSampler: local row ids, global column ids)."""
+    return sampling.PairSampler(graph.n, pos, n_cols=graph.n_cols,
+                                n_pos_global=_global_count(pos, graph) if n_pos_global is None else n_pos_global)
+
+
+def _graph_sampler(graph):
+    """The sampler whose positives are the graph's own entries (SupEdge, analyze_disentangle): kept with the graph."""
+    smp = graph.__dict__.get("_pair_sampler")
+    if smp is None:
+        smp = graph._pair_sampler = _sampler(graph, sampling.flat_edges(graph))
+    return smp
 
 
 def _pair_loss_value(base, h_lo, h_hi, labels, graph):
@@ -155,6 +164,12 @@ class Trainer(object):
             st = self._static = StaticStep(self, self._static_host, self._static_device)
         return st
 
+    def close(self):
+        """Drop the captured step (its HIP graph is destroyed here, by reference count: capture.StaticStep)."""
+        st = self.__dict__.pop("_static", None)
+        if st is not None:
+            st.close()
+
     def train_step_captured(self, *args):
         """train_step replayed from a HIP graph (unsharded graphs; the arguments must be the same objects every call).
         Returns the step's log dict - 0-d device tensors that the NEXT replay overwrites."""
@@ -166,7 +181,11 @@ class Trainer(object):
         return st(*args)
 
     def _static_host(self, *args):
-        pass
+        pass              # nothing: the pair samplers' generator state lives on the device (csrc/pair_sample.hip)
+
+    def samplers(self, *args):
+        """The PairSamplers this trainer draws from (main.run reads their event counters)."""
+        return []
 
     def analyze_disentangle(self, feature, adj):
         """trainer.py:82-134: how different are the heads?  Per layer: the head x head correlation of the raw scores
@@ -179,8 +198,7 @@ class Trainer(object):
         g = graph_of(adj)
         with torch.no_grad():
             feats = self.models[0].get_em(feature, adj, fusers)
-            pos = sampling.flat_edges(g)
-            indices, _ = _sample(g, pos, _global_count(pos, g))
+            indices, _ = _graph_sampler(g).sample()
             scores = self.models[0].predict_adjs_sparse(feature, adj, fusers, auxiliary_edges=[indices])
             at_cor, at_dist, feat_cor = [], [], []
             for layer in range(2):
@@ -207,12 +225,7 @@ class SupEdgeTrainer(Trainer):
         return graph_of(adj)
 
     def sample_train(self, gt):
-        g = graph_of(gt)
-        cached = g.__dict__.get("_flat_pos")
-        if cached is None:                    # the positive set of a graph never changes: keep it with the graph
-            pos = sampling.flat_edges(g)
-            cached = g._flat_pos = (pos, _global_count(pos, g))
-        idx, lab = _sample(g, *cached)
+        idx, lab = self._static_sampler(gt).sample()
         return lab, [idx]
 
     def inference(self, data, sparse_edge_index=None):
@@ -238,17 +251,13 @@ class SupEdgeTrainer(Trainer):
         return {"loss_heads_sup": loss.detach()}
 
     def _static_sampler(self, gt):
-        g = graph_of(gt)
-        smp = g.__dict__.get("_static_sampler")
-        if smp is None:
-            smp = g._static_sampler = sampling.StaticSampler(g.n, sampling.flat_edges(g), n_cols=g.n_cols)
-        return smp
+        return _graph_sampler(graph_of(gt))         # the positive set of a graph never changes: one sampler per graph
 
-    def _static_host(self, data, gt_adj=None):
-        self._static_sampler(gt_adj if gt_adj is not None else data[1]).draw_k()
+    def samplers(self, data, gt_adj=None):
+        return [self._static_sampler(gt_adj if gt_adj is not None else data[1])]
 
     def _static_device(self, adam, data, gt_adj=None):
-        indices, labels = self._static_sampler(gt_adj if gt_adj is not None else data[1]).sample()
+        indices, labels = self._static_sampler(gt_adj if gt_adj is not None else data[1]).sample_static()
         loss = self.loss(data, labels, [indices])
         self._static_finish(adam, loss)
         return {"loss_heads_sup": loss.detach()}
@@ -287,12 +296,13 @@ class GeneratedEdgeTrainer(Trainer):
         self.graph = g
         self.dis_adjs = [flat[same], flat[diff]]
         self.n_pos_global = [_global_count(p, g) for p in self.dis_adjs]
+        self._samplers = None
         return self.dis_adjs
 
     def sample_train(self):
         labs, idxs = [], []
-        for pos, n_glob in zip(self.dis_adjs, self.n_pos_global):
-            idx, lab = _sample(self.graph, pos, n_glob)
+        for smp in self._static_samplers():
+            idx, lab = smp.sample()
             labs.append(lab)
             idxs.append(idx)
         return labs, idxs
@@ -326,15 +336,14 @@ class GeneratedEdgeTrainer(Trainer):
 
     def _static_samplers(self):
         if self.__dict__.get("_samplers") is None:
-            self._samplers = [sampling.StaticSampler(self.graph.n, pos, n_cols=self.graph.n_cols) for pos in self.dis_adjs]
+            self._samplers = [_sampler(self.graph, pos, n) for pos, n in zip(self.dis_adjs, self.n_pos_global)]
         return self._samplers
 
-    def _static_host(self, data, pre_adjs=None):
-        for smp in self._static_samplers():
-            smp.draw_k()
+    def samplers(self, data=None, pre_adjs=None):
+        return self._static_samplers()
 
     def _static_device(self, adam, data, pre_adjs=None):
-        pairs = [smp.sample() for smp in self._static_samplers()]
+        pairs = [smp.sample_static() for smp in self._static_samplers()]
         loss = self.loss(data, [lab for _idx, lab in pairs], [idx for idx, _lab in pairs])
         self._static_finish(adam, loss)
         return {"loss_head_disen": loss.detach()}

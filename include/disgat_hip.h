@@ -30,6 +30,7 @@
  *  disgat_split_f16,    16-bit matrix cores (operand splitting), with the bias / additive / ELU (layers.py:508)
  *  disgat_amax,         / leaky-ReLU (layers.py:917, models.py:535) epilogues fused; weight preparation, the
  *  disgat_act_bwd       scale input and the activation's backward.
+ *  disgat_pair_sample_* the training-pair samplers of SupEdge / DisEdge (pretrainer.py:683-707, 524-576).
  *  disgat_adam_multi    the per-sub-module torch.optim.Adam steps of a trainer (trainer.py:58-60, 205-206) as one launch.
  *
  * Layouts (all row-major fp32 unless noted; "ld*" = row stride in floats, a multiple of 4,
@@ -76,7 +77,7 @@ extern "C" {
 
 typedef void* disgat_stream_t; /* hipStream_t */
 
-int disgat_abi_version(void);          /* 3 in this revision; changes with any launcher's argument list */
+int disgat_abi_version(void);          /* 4 in this revision; changes with any launcher's argument list */
 const char* disgat_last_error(void);
 
 /* Fused score -> sigmoid -> row softmax -> aggregation for all H heads of one layer.
@@ -287,6 +288,37 @@ int disgat_linear_skinny(const float* X, int64_t ldx, int64_t M, int K, const fl
  * partial [N][K] into partials [n_waves][N][K]; the caller adds them (fixed order: deterministic). */
 int disgat_linear_skinny_wgrad(const float* X, int64_t ldx, int64_t M, int K, const float* G, int64_t ldg, int N,
                                float* partials, int n_waves, disgat_stream_t stream);
+
+/* ---- SSL pair sampler ------------------------------------------------------------------------ */
+
+/* SupEdgeTrainer.sample_train / GeneratedEdgeTrainer.sample_train (pretrainer.py:683-707, 524-576) without the dense
+ * N x N tensors: the list  nonzero( (rand(N,N) < p) | {a uniform subset of exactly n_sel of the positives} )  in row-major
+ * order, with labels = "is a positive", drawn from a counter-based generator whose (seed, step) live on the device.
+ *   items    int32 [n_items][8] = {row, col_lo, col_hi, pos_lo, pos_hi, 0, 0, 0}, ordered by (row, col_lo): a partition of
+ *            every row's column range [0, n_cols) into intervals; positives [pos_lo, pos_hi) are those of the row whose
+ *            column lies in the interval - at most DISGAT_SAMPLE_PCAP of them - and (col_hi - col_lo) * p should not
+ *            exceed DISGAT_SAMPLE_RMEAN (an item keeps at most DISGAT_SAMPLE_RCAP random columns; meta[4] counts items
+ *            that hit either limit).  One wave per item, items_per_wave (1..16) consecutive items per wave.
+ *   pos_col  int32 [n_pos]: columns of the positives, row-major (a CSR column array: sorted inside a row)
+ *   p        the Bernoulli probability of the random part (the reference's edge_ratio * 3), in [0, 1]
+ *   meta     int64 [8], device: [0] seed, [1] step (the plan advances it), [2] the step the last plan drew with,
+ *            [3] length of the last list (clamped to capacity), [4] / [5] event counters: item / list over capacity.
+ * disgat_pair_sample_plan  counts (item_count [n_items], block_count / block_off [ceil(n_items / (4 * items_per_wave))]
+ *            scratch), leaves the list length in meta[3] and, as a double, in *count_out (NULL: not wanted).
+ * disgat_pair_sample_emit  writes idx_out int64 [2][capacity] (rows, then columns) and lab_out [capacity] for the plan that
+ *            preceded it on the stream; entries beyond `capacity` are dropped; pad_tail != 0 fills [length, capacity) with
+ *            the pair (n_rows - 1, n_cols - 1) and label -1 (the padding disgat_pair_loss skips).
+ * A caller that wants a list of exact length reads meta[3] between the two calls and passes it as the capacity. */
+#define DISGAT_SAMPLE_PCAP 256
+#define DISGAT_SAMPLE_RCAP 256
+#define DISGAT_SAMPLE_RMEAN 96
+int disgat_pair_sample_plan(const int32_t* items, int n_items, int items_per_wave, const int32_t* pos_col, int64_t n_pos,
+                            int64_t n_sel, double p, int64_t capacity, int64_t* meta, int32_t* item_count,
+                            int32_t* block_count, int64_t* block_off, double* count_out, disgat_stream_t stream);
+int disgat_pair_sample_emit(const int32_t* items, int n_items, int items_per_wave, const int32_t* pos_col, int64_t n_pos,
+                            int64_t n_sel, double p, int64_t n_rows, int64_t n_cols, int64_t capacity, int64_t* meta,
+                            const int32_t* item_count, const int64_t* block_off, int64_t* idx_out, float* lab_out,
+                            int pad_tail, disgat_stream_t stream);
 
 /* ---- optimiser --------------------------------------------------------------------------- */
 

@@ -73,8 +73,8 @@ def test_captured_run_equals_the_eager_static_run(golden_dir):
         if captured:
             assert all(t.static_step().graph is not None for t in [ct] + trs)
             assert ct.static_step().replays == 8 and trs[0].static_step().replays == 4
-        smp = data[1].__dict__["_static_sampler"]
-        assert int(smp.short) == 0 and smp.clamped == 0
+        smp = data[1].__dict__["_pair_sampler"]
+        assert smp.events() == (0, 0) and int(smp.meta[1]) == 4           # one list per SupEdge step, none for warm-up or capture
         runs.append((torch.stack(losses).cpu(), _params(ct, trs), [o.state_dict() for o in ct.models_opt]))
     assert torch.isfinite(runs[0][0]).all()
     assert torch.equal(runs[0][0], runs[1][0]), (runs[0][0], runs[1][0])

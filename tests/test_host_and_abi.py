@@ -68,13 +68,17 @@ def test_transpose_structure():
 
 
 def test_sampler_matches_reference_structure(golden_dir):
+    """The sampler's CPU restatement (the product is a HIP kernel held to equality with it, tests/test_gpu_sampler.py)."""
     from edgedisentangle_ssl_amd import sampling
     from edgedisentangle_ssl_amd.graph import CSRGraph
+    from oracle import sampler_oracle as so
     idx, vals, n = ic.tiny_graph()
     g = CSRGraph.from_index(idx, n)
     pos = sampling.flat_edges(g)
-    gen = torch.Generator().manual_seed(3)
-    pidx, lab = sampling.sample_pairs(n, pos, gen)
+    p = 3.0 * g.nnz / (n * n)
+    items = sampling.build_items(pos, n, n, p).numpy()
+    r, c, lab, _over = so.sample(items, g.col.numpy(), g.nnz // 3, p, 3, 0, n)
+    pidx, lab = torch.from_numpy(np.stack([r, c])), torch.from_numpy(lab)
     flat = pidx[0] * n + pidx[1]
     assert torch.all(flat[1:] > flat[:-1])                   # row-major, unique (mask.nonzero() order)
     assert torch.equal(lab, torch.isin(flat, pos).float())

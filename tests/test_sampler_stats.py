@@ -1,13 +1,16 @@
-"""Distribution of the O(E) pair sampler (sampling.sample_pairs) against the reference's dense-mask sampler
-(pretrainer.py:683-707, 524-576): mask = Bernoulli(3*rho) over all N^2 entries united with a third of the
-positives.  The reference's own draw on the tiny graph is recorded in tests/golden/tiny_ref_sampler.npz; one draw
-cannot be matched entry for entry (different RNG streams), so the test compares distributions:
+"""Distribution of the pair sampler against the reference's dense-mask sampler (pretrainer.py:683-707, 524-576):
+mask = Bernoulli(3*rho) over all N^2 entries united with a third of the positives.  The reference's own draw on the tiny
+graph is recorded in tests/golden/tiny_ref_sampler.npz; one draw cannot be matched entry for entry (different RNG
+streams), so the tests compare distributions:
   * M = K + n_pos//3 - overlap with K ~ Binomial(N^2, 3 rho): mean and spread of our M over many draws against the
     closed form, and the reference's recorded M inside that spread;
   * every positive appears with probability 1/3 + 2/3 * 3 rho, every negative with probability 3 rho;
-  * the random part is uniform over rows (per-row counts are Binomial(N, 3 rho));
+  * the random part is uniform over rows and columns (per-row counts are Binomial(N, 3 rho));
+  * EXACTLY n_pos // 3 positives are forced on (the reference takes the first third of a shuffle);
   * structure: row-major sorted, unique, labels == membership.
-Runs on the CPU here and on the GPU (the sampler is device code only through torch ops)."""
+The product is a HIP kernel (csrc/pair_sample.hip); oracle/sampler_oracle.py restates it draw for draw in numpy.  Here (CPU)
+the statistics are checked on the oracle, together with the host-side work-item builder; on the GPU the same statistics are
+checked on the kernel itself, and tests/test_gpu_sampler.py holds the kernel to EQUALITY with the oracle."""
 import os
 
 import numpy as np
@@ -17,28 +20,48 @@ import torch
 import inputs_common as ic
 
 
-def _stats(dev, golden_dir, draws=600, static=False):
+class _OracleSampler:
+    """sampling.PairSampler's interface on the numpy restatement."""
+
+    def __init__(self, n_rows, pos_flat, n_cols=None, n_pos_global=None, seed=0):
+        from oracle import sampler_oracle as so
+        self.so = so
+        self.n_rows, self.n_cols = n_rows, n_rows if n_cols is None else n_cols
+        pos = np.asarray(pos_flat, dtype=np.int64)
+        self.npos = pos.shape[0]
+        n_glob = self.npos if n_pos_global is None else n_pos_global
+        self.p = min(1.0, 3.0 * n_glob / (float(self.n_cols) ** 2))
+        rowptr = np.searchsorted(pos, np.arange(self.n_rows + 1, dtype=np.int64) * self.n_cols)
+        self.col = pos % self.n_cols
+        self.items = so.build_items(rowptr, self.col, self.n_rows, self.n_cols, self.p)
+        self.seed, self.step, self.over = seed, 0, 0
+
+    def sample(self):
+        r, c, lab, over = self.so.sample(self.items, self.col, self.npos // 3, self.p, self.seed, self.step, self.n_cols)
+        self.step += 1
+        self.over += over
+        return torch.from_numpy(np.stack([r, c])), torch.from_numpy(lab)
+
+
+def _stats(make, dev, golden_dir, draws=600, static=False):
     from edgedisentangle_ssl_amd import sampling
     from edgedisentangle_ssl_amd.graph import CSRGraph
     idx, _vals, n = ic.tiny_graph()
     g = CSRGraph.from_index(idx.to(dev), n)
     pos = sampling.flat_edges(g)
     npos = int(pos.numel())
-    gen = torch.Generator(device=dev).manual_seed(11)
-    hgen = torch.Generator().manual_seed(12)
     p3 = 3.0 * npos / (n * n)
-    ms, hit = [], torch.zeros(n * n, device=dev)
-    smp = sampling.StaticSampler(n, pos) if static else None
+    ms, hit, forced = [], torch.zeros(n * n, device=dev), []
+    smp = make(n, pos)
     for _ in range(draws):
         if static:      # the fixed-capacity form captured steps use: valid prefix + padding (label -1, pair (n-1, n-1))
-            smp.draw_k(hgen)
-            pidx, lab = smp.sample(gen)
+            pidx, lab = smp.sample_static()
             c = int(lab._disgat_count)
             assert pidx.shape[1] == smp.capacity == lab.shape[0] and getattr(pidx, "_disgat_static", False)
             assert torch.all(lab[c:] == -1) and torch.all(pidx[:, c:] == n - 1)
             pidx, lab = pidx[:, :c], lab[:c]
         else:
-            pidx, lab = sampling.sample_pairs(n, pos, gen, host_generator=hgen)
+            pidx, lab = smp.sample()
         flat = pidx[0] * n + pidx[1]
         assert torch.all(flat[1:] > flat[:-1])                       # mask.nonzero() order, no duplicates
         assert torch.equal(lab, torch.isin(flat, pos).float())
@@ -50,8 +73,8 @@ def _stats(dev, golden_dir, draws=600, static=False):
     # E[M] = N^2 p3 + third * (1 - p3);  Var[M] = (N^2 - third) p3 (1 - p3)   (entries outside the third are Bernoulli)
     mean = n * n * p3 + third * (1 - p3)
     var = (n * n - third) * p3 * (1 - p3)
-    if static:
-        assert int(smp.short) == 0 and smp.clamped == 0
+    if hasattr(smp, "events"):
+        assert smp.events() == (0, 0)
     assert abs(ms.mean() - mean) < 4 * np.sqrt(var / draws), (ms.mean(), mean)
     assert 0.8 * var < ms.var() < 1.25 * var, (ms.var(), var)
     ref = np.load(os.path.join(golden_dir, "tiny_ref_sampler.npz"))
@@ -63,6 +86,8 @@ def _stats(dev, golden_dir, draws=600, static=False):
     is_pos[pos.cpu().numpy()] = True
     p_pos = third / npos + (1 - third / npos) * p3
     assert abs(freq[is_pos].mean() - p_pos) < 4 * np.sqrt(p_pos * (1 - p_pos) / (draws * is_pos.sum()))
+    # every single positive at its own rate (the forced third is a fresh uniform subset every draw, not a fixed one)
+    assert np.all(np.abs(freq[is_pos] - p_pos) < 5.5 * np.sqrt(p_pos * (1 - p_pos) / draws)), np.abs(freq[is_pos] - p_pos).max()
     assert abs(freq[~is_pos].mean() - p3) < 4 * np.sqrt(p3 * (1 - p3) / (draws * (~is_pos).sum()))
     per_row = freq.reshape(n, n)[:, :].copy()
     per_row[is_pos.reshape(n, n)] = np.nan                           # negatives only: uniform over rows and columns
@@ -72,33 +97,91 @@ def _stats(dev, golden_dir, draws=600, static=False):
     assert np.all(np.abs(cols - p3) < 6 * np.sqrt(p3 * (1 - p3) / (draws * (n - 24)))), cols
 
 
-def test_sampler_distribution_cpu(golden_dir):
-    _stats(torch.device("cpu"), golden_dir)
-
-
-def test_static_sampler_distribution_cpu(golden_dir):
-    _stats(torch.device("cpu"), golden_dir, static=True)
+def test_sampler_distribution_oracle(golden_dir):
+    _stats(lambda n, pos: _OracleSampler(n, pos.numpy(), seed=11), torch.device("cpu"), golden_dir)
 
 
 @pytest.mark.gpu
 def test_static_sampler_distribution_gpu(golden_dir):
-    _stats(torch.device("cuda:0"), golden_dir, static=True)
+    from edgedisentangle_ssl_amd import sampling
+    _stats(lambda n, pos: sampling.PairSampler(n, pos, seed=11), torch.device("cuda:0"), golden_dir, static=True)
 
 
 @pytest.mark.gpu
 def test_sampler_distribution_gpu(golden_dir):
-    _stats(torch.device("cuda:0"), golden_dir)
-
-
-def test_binomial_count_and_subset():
     from edgedisentangle_ssl_amd import sampling
-    g = torch.Generator().manual_seed(0)
-    ks = np.array([sampling.binomial_count(10 ** 12, 6e-5, g) for _ in range(200)], dtype=np.float64)
-    assert abs(ks.mean() - 6e7) < 4 * np.sqrt(6e7 / 200) and 0.7 * 6e7 < ks.var() < 1.4 * 6e7
-    assert sampling.binomial_count(0, 0.5) == 0 and sampling.binomial_count(10, 0.0) == 0
-    s = sampling.uniform_subset(50, 45, torch.device("cpu"), g)       # dense case: many collisions, still 45 distinct
-    assert s.numel() == 45 and torch.all(s[1:] > s[:-1]) and int(s.max()) < 50
-    assert sampling.uniform_subset(10, 99, torch.device("cpu"), g).numel() == 10
+    _stats(lambda n, pos: sampling.PairSampler(n, pos, seed=12), torch.device("cuda:0"), golden_dir)
+
+
+def test_exactly_a_third_of_the_positives_is_forced_on():
+    """pretrainer.py:697-700: indices[:edge_num] of a shuffle - a uniform subset of exactly n_pos // 3.  With the random part
+    switched off (p = 0) the list IS that subset; over many steps every positive is in it a third of the time."""
+    from oracle import sampler_oracle as so
+    rng = np.random.default_rng(5)
+    n = 200
+    pos = np.unique(rng.integers(0, n * n, 1000))
+    rowptr = np.searchsorted(pos, np.arange(n + 1, dtype=np.int64) * n)
+    items = so.build_items(rowptr, pos % n, n, n, 0.0)
+    hits = np.zeros(pos.shape[0])
+    for step in range(300):
+        r, c, lab, over = so.sample(items, pos % n, pos.shape[0] // 3, 0.0, 77, step, n)
+        assert r.shape[0] == pos.shape[0] // 3 and np.all(lab == 1) and over == 0
+        hits += np.isin(pos, r * n + c)
+    assert np.all(np.abs(hits / 300 - 1 / 3) < 5.5 * np.sqrt(2 / 9 / 300)), np.abs(hits / 300 - 1 / 3).max()
+    # pairwise: neighbouring positives are in the same third with probability 1/3 * (k - 1) / (n_pos - 1) (no sticky pairs)
+    k = pos.shape[0] // 3
+    picks = []
+    for step in range(200):
+        r, c, _lab, _over = so.sample(items, pos % n, k, 0.0, 78, step, n)
+        picks.append(np.isin(pos, r * n + c))
+    a = np.stack(picks)
+    both = (a[:, :-1] & a[:, 1:]).mean()
+    assert abs(both - (1 / 3) * ((k - 1) / (pos.shape[0] - 1))) < 0.01, both
+
+
+def test_dense_and_empty_corners():
+    """p = 1 switches every entry on (rows of 3 N positives and more); no positives: the Bernoulli part alone."""
+    from oracle import sampler_oracle as so
+    n = 40
+    full = np.arange(n * n, dtype=np.int64)
+    rowptr = np.arange(n + 1, dtype=np.int64) * n
+    items = so.build_items(rowptr, full % n, n, n, 1.0)
+    r, c, lab, over = so.sample(items, full % n, (n * n) // 3, 1.0, 3, 0, n)
+    assert np.array_equal(r * n + c, full) and np.all(lab == 1) and over == 0
+    empty = np.zeros(0, dtype=np.int64)
+    items = so.build_items(np.zeros(n + 1, dtype=np.int64), empty, n, n, 0.05)
+    sizes = [so.sample(items, empty, 0, 0.05, 3, s, n)[0].shape[0] for s in range(400)]
+    assert abs(np.mean(sizes) - n * n * 0.05) < 4 * np.sqrt(n * n * 0.05 * 0.95 / 400)
+
+
+def test_item_tables_host_builder_equals_the_oracle():
+    """sampling.build_items (torch, the product's host side) against the oracle's per-row loop: the tiny graph, a hub row of
+    1 000 positives (cut every PCAP-th positive), a dense mask (several column blocks per row), a row shard (more columns
+    than rows); and the invariants the kernels rely on."""
+    from edgedisentangle_ssl_amd import sampling
+    from oracle import sampler_oracle as so
+    rng = np.random.default_rng(9)
+    cases = []
+    idx, _v, n = ic.tiny_graph()
+    flat = np.unique((idx[0] * n + idx[1]).numpy())
+    cases.append((n, n, flat, None))
+    hub = np.concatenate([7 * 3000 + rng.choice(3000, 1000, replace=False), rng.integers(0, 500 * 3000, 4000)])
+    cases.append((500, 3000, np.unique(hub), None))
+    cases.append((50, 50, np.unique(rng.integers(0, 2500, 900)), None))                 # p ~ 0.8: column blocks of ~118 > n: one block; then
+    cases.append((30, 2000, np.unique(rng.integers(0, 30 * 2000, 20000)), 400000))      # p = 0.3: blocks of 320 columns
+    for n_rows, n_cols, pos, n_glob in cases:
+        p = min(1.0, 3.0 * (pos.shape[0] if n_glob is None else n_glob) / float(n_cols) ** 2)
+        mine = sampling.build_items(torch.from_numpy(pos), n_rows, n_cols, p).numpy()
+        rowptr = np.searchsorted(pos, np.arange(n_rows + 1, dtype=np.int64) * n_cols)
+        ref = so.build_items(rowptr, pos % n_cols, n_rows, n_cols, p)
+        assert np.array_equal(mine, ref), (n_rows, n_cols)
+        row, clo, chi, plo, phi = (mine[:, i].astype(np.int64) for i in range(5))
+        assert np.all(phi - plo <= so.PCAP) and np.all(chi > clo) and np.all((chi - clo) * p <= so.RMEAN + 1)
+        assert plo[0] == 0 and phi[-1] == pos.shape[0] and np.array_equal(plo[1:], phi[:-1])
+        assert np.all(np.diff(row * n_cols + clo) > 0)
+        cover = np.zeros(n_rows, dtype=np.int64)
+        np.add.at(cover, row, chi - clo)
+        assert np.all(cover == n_cols)                                    # a partition of every row
 
 
 def test_sampler_on_a_row_shard():
@@ -108,13 +191,12 @@ def test_sampler_on_a_row_shard():
     idx, _vals, n = ic.tiny_graph()
     g = CSRGraph.from_index(idx, n)
     full = set((g.row * n + g.col.long()).tolist())
-    gen = torch.Generator().manual_seed(5)
     seen_pos = 0
     for rank in range(3):
         dg = parallel.DistGraph.shard(g, rank, 3)
         pos = sampling.flat_edges(dg)
         assert torch.all(pos[1:] > pos[:-1])
-        pidx, lab = sampling.sample_pairs(dg.n, pos, gen, n_cols=dg.n_cols, n_pos_global=g.nnz)
+        pidx, lab = _OracleSampler(dg.n, pos.numpy(), n_cols=dg.n_cols, n_pos_global=g.nnz, seed=5 + rank).sample()
         assert int(pidx[0].max()) < dg.n and int(pidx[1].max()) < n and int(pidx[1].max()) >= dg.n   # columns span all nodes
         glob = ((pidx[0] + dg.row_start) * n + pidx[1]).tolist()
         assert [float(f in full) for f in glob] == lab.tolist()
@@ -123,10 +205,10 @@ def test_sampler_on_a_row_shard():
 
 
 def test_ranks_draw_their_own_streams_and_pool_to_the_unsharded_sample():
-    """main.run reseeds every rank after the replicated set-up (main.reseed_rank): two equal-size shards must not score
-    the same (local row, column) negatives, a rank's stream must be repeatable, and the lists pooled over the ranks
-    must have the unsharded sample's size distribution (K ~ Binomial(N^2, 3 rho) random entries + a third of the
-    positives)."""
+    """main.run reseeds every rank after the replicated set-up (main.reseed_rank) and a sampler takes its seed from torch's
+    CPU generator at first use: two equal-size shards must not score the same (local row, column) negatives, a rank's stream
+    must be repeatable, and the lists pooled over the ranks must have the unsharded sample's size distribution
+    (K ~ Binomial(N^2, 3 rho) random entries + a third of the positives)."""
     from edgedisentangle_ssl_amd import main as drop_in
     from edgedisentangle_ssl_amd import sampling
     n, world = 64, 2
@@ -138,25 +220,34 @@ def test_ranks_draw_their_own_streams_and_pool_to_the_unsharded_sample():
     shards = []
     for r in range(world):
         own = flat_all[(flat_all // n >= r * half) & (flat_all // n < (r + 1) * half)]
-        shards.append(torch.from_numpy(own - r * half * n))            # local rows, global columns
+        shards.append(own - r * half * n)                               # local rows, global columns
     totals, same = [], 0
+
+    def seeded(r, rep):
+        drop_in.reseed_rank(1000 + rep, r)
+        seed = int(torch.randint(0, sampling._I64_MAX, (1,), dtype=torch.int64).item())      # PairSampler._ensure_seed
+        return _OracleSampler(half, shards[r], n_cols=n, n_pos_global=npos, seed=seed)
     for rep in range(200):
         lists = []
         for r in range(world):
-            drop_in.reseed_rank(1000 + rep, r)
-            idx, lab = sampling.sample_pairs(half, shards[r], n_cols=n, n_pos_global=npos)
-            assert torch.equal(lab, torch.isin(idx[0] * n + idx[1], shards[r]).float())
+            idx, lab = seeded(r, rep).sample()
+            assert torch.equal(lab, torch.isin(idx[0] * n + idx[1], torch.from_numpy(shards[r])).float())
             lists.append(idx)
-        drop_in.reseed_rank(1000 + rep, 1)
-        again, _ = sampling.sample_pairs(half, shards[1], n_cols=n, n_pos_global=npos)
+        again, _ = seeded(1, rep).sample()
         assert torch.equal(again, lists[1])                             # a rank's stream repeats under its seed
         neg = [set((i[0] * n + i[1]).tolist()) - set(s.tolist()) for i, s in zip(lists, shards)]
         same += len(neg[0] & neg[1]) / max(1, min(len(neg[0]), len(neg[1])))
         totals.append(sum(i.shape[1] for i in lists))
     assert same / 200 < 0.3, same / 200             # identical streams share ~all negatives, independent ones ~3 rho = 0.11
-    third = sum(int(s.numel()) // 3 for s in shards)
+    third = sum(int(s.size) // 3 for s in shards)
     mean = n * n * p3 + third * (1 - p3)
     var = (n * n - third) * p3 * (1 - p3)
     t = np.asarray(totals, dtype=np.float64)
     assert abs(t.mean() - mean) < 4 * np.sqrt(var / t.size), (t.mean(), mean)
     assert 0.7 * var < t.var() < 1.4 * var, (t.var(), var)
+
+
+def test_no_cpu_path():
+    from edgedisentangle_ssl_amd import sampling
+    with pytest.raises(RuntimeError):
+        sampling.PairSampler(4, torch.tensor([1, 5], dtype=torch.int64))
