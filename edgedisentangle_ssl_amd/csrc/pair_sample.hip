@@ -7,11 +7,13 @@
 //   * the Bernoulli(3 rho) part is a Bernoulli process along every row, and a Bernoulli process restricted to disjoint column
 //     intervals is independent per interval.  A work item is one interval (row, [col_lo, col_hi)) holding at most kPCap
 //     positives and an expected <= ~96 random entries; ONE WAVE walks it by geometric skipping: every lane draws a gap
-//     G = floor(log(U) / log(1 - p)) from a counter-based generator (Philox4x32-10), an in-wave inclusive scan of G + 1 gives
+//     G = floor(log(U) / log(1 - p)) from a counter-based generator (Philox2x32-10), an in-wave inclusive scan of G + 1 gives
 //     64 sorted, distinct columns per round - exactly the iid Bernoulli(p) process, already sorted and de-duplicated;
 //   * "a third of the shuffled positives" is a uniform subset of EXACTLY floor(n_pos / 3) positives.  Positive j is in it
-//     iff pi(j) < n_pos / 3 for a keyed pseudo-random PERMUTATION pi of [0, n_pos) (8-round Feistel network on the smallest
-//     even bit width + cycle walking): a bijection, so the count is exact, with no pass over the positives and no state;
+//     iff pi(j) < n_pos / 3 for a keyed pseudo-random PERMUTATION pi of [0, n_pos): an 8-round alternating Feistel network on
+//     Z_a x Z_b, a = 2^k ~ sqrt(n_pos), b = ceil(n_pos / a) (xor on the power-of-two side, addition mod b on the other), with
+//     cycle walking over the < a surplus values (one in ~sqrt(n_pos)): a bijection, so the count is exact, with no pass over
+//     the positives and no state;
 //   * the wave merges the two sorted sets by rank (own index + lower bound in the other set, both sets in LDS), labels fall
 //     out of the merge (a random column that coincides with any positive of the row has label 1);
 //   * output offsets come from one prefix sum over per-block counts: count pass -> one-block scan -> emit pass (the emit pass
@@ -67,25 +69,21 @@ __device__ __forceinline__ Keys make_keys(uint64_t seed, uint64_t step) {
   return k;
 }
 
-// Philox4x32-10 (Salmon et al. 2011); returns the first two output words as one 64-bit value.
-__device__ __forceinline__ uint64_t philox_u64(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+// Philox2x32-10 (Salmon et al. 2011): 64-bit counter (c0, c1), 32-bit key; returns both output words as one 64-bit value.
+__device__ __forceinline__ uint64_t philox_u64(uint32_t c0, uint32_t c1, uint32_t key) {
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
-    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
-    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
-    const uint32_t n1 = (uint32_t)p1;
-    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
-    const uint32_t n3 = (uint32_t)p0;
-    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-    k0 += 0x9E3779B9u;
-    k1 += 0xBB67AE85u;
+    const uint64_t p = (uint64_t)0xD256D193u * c0;
+    c0 = (uint32_t)(p >> 32) ^ key ^ c1;
+    c1 = (uint32_t)p;
+    key += 0x9E3779B9u;
   }
   return ((uint64_t)c0 << 32) | c1;
 }
 
 // ln(u) for u in (0, 1], as a fixed sequence of correctly rounded double operations: u = m 2^e with m in [sqrt(1/2), sqrt 2),
-// s = (m - 1) / (m + 1), ln m = 2 s (1 + z/3 + z^2/5 + ... + z^11/23), z = s^2 <= 0.0295 (truncation < 1e-18 relative).
+// s = (m - 1) / (m + 1), ln m = 2 s (1 + z/3 + z^2/5 + ... + z^7/15), z = s^2 <= 0.0295 (truncation < 4e-14 relative: a gap
+// changes where log(u) / log(1 - p) lies that close to an integer - one draw in 10^13).
 // No contraction into fused multiply-adds from here to the end of the file: the oracle rounds after every operation.
 #pragma clang fp contract(off)
 __device__ __forceinline__ double det_log(double u) {
@@ -97,11 +95,7 @@ __device__ __forceinline__ double det_log(double u) {
   }
   const double s = (m - 1.0) / (m + 1.0);
   const double z = s * s;
-  double p = 1.0 / 23.0;
-  p = p * z + 1.0 / 21.0;
-  p = p * z + 1.0 / 19.0;
-  p = p * z + 1.0 / 17.0;
-  p = p * z + 1.0 / 15.0;
+  double p = 1.0 / 15.0;
   p = p * z + 1.0 / 13.0;
   p = p * z + 1.0 / 11.0;
   p = p * z + 1.0 / 9.0;
@@ -130,20 +124,23 @@ __device__ __forceinline__ uint32_t scan_sat(uint32_t v, uint32_t cap, int lane)
   return v;
 }
 
-__device__ __forceinline__ uint32_t feistel(uint32_t v, const Keys& k, int half, uint32_t mask) {
-  uint32_t L = v >> half, R = v & mask;
+// One pass of the permutation network over Z_a x Z_b (v = R * a + L, a = 2^ka, b = fb): even rounds L ^= F(R) mod a, odd rounds
+// R = (R + F(L) mod b) mod b, the reduction of the 32-bit F to [0, b) by multiply-shift.  Every round is invertible.
+__device__ __forceinline__ uint32_t feistel(uint32_t v, const Keys& k, int ka, uint32_t fb) {
+  const uint32_t amask = (1u << ka) - 1u;
+  uint32_t L = v & amask, R = v >> ka;
 #pragma unroll
-  for (int r = 0; r < kFeistelRounds; ++r) {
-    const uint32_t t = L ^ (fmix32(R + k.fk[r]) & mask);
-    L = R;
-    R = t;
+  for (int r = 0; r < kFeistelRounds; r += 2) {
+    L ^= fmix32(R + k.fk[r]) & amask;
+    R += __umulhi(fmix32(L + k.fk[r + 1]), fb);
+    R = R >= fb ? R - fb : R;
   }
-  return (L << half) | R;
+  return (R << ka) | L;
 }
 
-__device__ __forceinline__ bool selected(uint32_t j, const Keys& k, int half, uint32_t mask, uint32_t n_pos, uint32_t n_sel) {
+__device__ __forceinline__ bool selected(uint32_t j, const Keys& k, int ka, uint32_t fb, uint32_t n_pos, uint32_t n_sel) {
   uint32_t v = j;
-  do v = feistel(v, k, half, mask);               // cycle walking: j < n_pos lies on a cycle that re-enters [0, n_pos)
+  do v = feistel(v, k, ka, fb);                   // cycle walking: j < n_pos lies on a cycle that re-enters [0, n_pos)
   while (v >= n_pos);
   return v < n_sel;
 }
@@ -169,8 +166,8 @@ struct Params {
   int n_items, ipw;
   const int32_t* pos_col;
   uint32_t n_pos, n_sel;
-  int fhalf;
-  uint32_t fmask;
+  int fka;                     // the permutation's domain: Z_(2^fka) x Z_fb >= n_pos
+  uint32_t fb;
   double inv_log1m_p;          // 1 / log(1 - p); has_random = 0 when p <= 0
   int has_random;
   int64_t* meta;               // [0] seed  [1] step  [2] step of the last plan  [3] length of the last list  [4] events: item over capacity  [5] events: list over capacity
@@ -200,7 +197,7 @@ __device__ __forceinline__ int process_item(const Params& pr, const Keys& keys, 
         const uint32_t c = (uint32_t)pr.pos_col[j];
         pc[q] = c;
         myc[k] = c;
-        if (pr.n_sel) sel = selected(j, keys, pr.fhalf, pr.fmask, pr.n_pos, pr.n_sel);
+        if (pr.n_sel) sel = selected(j, keys, pr.fka, pr.fb, pr.n_pos, pr.n_sel);
       }
       selm[k] = __ballot(sel);
     }
@@ -212,7 +209,7 @@ __device__ __forceinline__ int process_item(const Params& pr, const Keys& keys, 
     const uint32_t chi = (uint32_t)it.chi;
     const uint32_t cap = chi - first + 1u;
     for (uint32_t round = 0; first < chi; ++round) {
-      const uint64_t bits = philox_u64((uint32_t)item_id, round * 64u + lane, 0x5A4D504Cu, 0u, keys.k0, keys.k1);
+      const uint64_t bits = philox_u64((uint32_t)item_id ^ keys.k1, round * 64u + lane, keys.k0);
       const uint32_t inc = draw_increment(bits, pr.inv_log1m_p, cap);
       const uint32_t incl = scan_sat(inc, cap, lane);
       const bool valid = incl <= chi - first;
@@ -387,10 +384,10 @@ int make_params(Params& pr, const int32_t* items, int n_items, int items_per_wav
   pr.pos_col = pos_col;
   pr.n_pos = (uint32_t)n_pos;
   pr.n_sel = (uint32_t)n_sel;
-  int bits = 2;
-  while ((int64_t(1) << bits) < n_pos) bits += 2;       // smallest even width covering the positives: < 4 x n_pos walk states
-  pr.fhalf = bits / 2;
-  pr.fmask = (1u << pr.fhalf) - 1u;
+  int bits = 0;
+  while ((int64_t(1) << bits) < n_pos) ++bits;           // a = 2^(bits / 2) ~ sqrt(n_pos), b = ceil(n_pos / a): a b - n_pos < a
+  pr.fka = bits / 2;
+  pr.fb = n_pos > 0 ? (uint32_t)((n_pos + (int64_t(1) << pr.fka) - 1) >> pr.fka) : 1u;
   pr.has_random = p > 0.0;
   pr.inv_log1m_p = p > 0.0 ? 1.0 / log1p(-p) : 0.0;     // p = 1: -0.0, every gap is 0
   pr.meta = meta;

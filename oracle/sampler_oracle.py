@@ -7,7 +7,7 @@ What it restates: SupEdgeTrainer.sample_train / GeneratedEdgeTrainer.sample_trai
     labels = (adj != 0) at those entries
 
 in the O(output) formulation of edgedisentangle_ssl_amd/csrc/pair_sample.hip, draw for draw: the same counter-based
-generator (Philox4x32-10 keyed by splitmix64(seed, step)), the same geometric skipping along column intervals with the
+generator (Philox2x32-10 keyed by splitmix64(seed, step)), the same geometric skipping along column intervals with the
 same explicit double-precision logarithm, the same Feistel permutation selecting exactly n_pos // 3 positives.  The
 outputs are integers, so the GPU tests demand EQUALITY with this file (tests/test_gpu_sampler.py); the distribution itself
 is pinned against the reference in tests/test_sampler_stats.py (closed-form moments of the reference's mask and the
@@ -48,20 +48,15 @@ def fmix32(h):
     return h ^ (h >> np.uint64(16))
 
 
-def philox_u64(c0, c1, c2, c3, k0, k1):
-    """Philox4x32-10; counters are uint64 arrays holding 32-bit values.  Returns (word0 << 32) | word1."""
-    c0, c1, c2, c3 = (np.asarray(c, dtype=np.uint64) for c in np.broadcast_arrays(c0, c1, c2, c3))
-    k0, k1 = int(k0), int(k1)
+def philox_u64(c0, c1, key):
+    """Philox2x32-10; counters are uint64 arrays holding 32-bit values.  Returns (word0 << 32) | word1."""
+    c0, c1 = (np.asarray(c, dtype=np.uint64) for c in np.broadcast_arrays(c0, c1))
+    key = int(key)
     for _ in range(10):
-        p0 = np.uint64(0xD2511F53) * c0
-        p1 = np.uint64(0xCD9E8D57) * c2
-        n0 = (p1 >> np.uint64(32)) ^ c1 ^ np.uint64(k0)
-        n1 = p1 & _M32
-        n2 = (p0 >> np.uint64(32)) ^ c3 ^ np.uint64(k1)
-        n3 = p0 & _M32
-        c0, c1, c2, c3 = n0, n1, n2, n3
-        k0 = (k0 + 0x9E3779B9) & 0xFFFFFFFF
-        k1 = (k1 + 0xBB67AE85) & 0xFFFFFFFF
+        p = np.uint64(0xD256D193) * c0
+        c0 = (p >> np.uint64(32)) ^ np.uint64(key) ^ c1
+        c1 = p & _M32
+        key = (key + 0x9E3779B9) & 0xFFFFFFFF
     return (c0 << np.uint64(32)) | c1
 
 
@@ -74,34 +69,37 @@ def det_log(u):
     e = np.where(low, e - 1, e)
     s = (m - 1.0) / (m + 1.0)
     z = s * s
-    p = np.full_like(z, 1.0 / 23.0)
-    for k in (21, 19, 17, 15, 13, 11, 9, 7, 5, 3):
+    p = np.full_like(z, 1.0 / 15.0)
+    for k in (13, 11, 9, 7, 5, 3):
         p = p * z + 1.0 / k
     p = p * z + 1.0
     lm = (2.0 * s) * p
     return e.astype(np.float64) * 0.69314718055994530942 + lm
 
 
-def feistel_bits(n_pos):
-    bits = 2
+def feistel_domain(n_pos):
+    """(ka, b): the permutation lives on Z_(2^ka) x Z_b, 2^ka ~ sqrt(n_pos), b = ceil(n_pos / 2^ka)."""
+    bits = 0
     while (1 << bits) < n_pos:
-        bits += 2
-    return bits
+        bits += 1
+    ka = bits // 2
+    return ka, (n_pos + (1 << ka) - 1) >> ka if n_pos > 0 else 1
 
 
 def selected(j, fk, n_pos, n_sel):
     """j: uint64 array of positive ids < n_pos -> bool: pi(j) < n_sel."""
-    half = feistel_bits(n_pos) // 2
-    mask = np.uint64((1 << half) - 1)
+    ka, b = feistel_domain(n_pos)
+    amask, ub = np.uint64((1 << ka) - 1), np.uint64(b)
     v = np.asarray(j, dtype=np.uint64).copy()
     todo = np.ones(v.shape, dtype=bool)
     while todo.any():
         w = v[todo]
-        left, right = w >> np.uint64(half), w & mask
-        for r in range(FEISTEL_ROUNDS):
-            t = left ^ (fmix32((right + np.uint64(fk[r])) & _M32) & mask)
-            left, right = right, t
-        w = (left << np.uint64(half)) | right
+        left, right = w & amask, w >> np.uint64(ka)
+        for r in range(0, FEISTEL_ROUNDS, 2):
+            left = left ^ (fmix32((right + np.uint64(fk[r])) & _M32) & amask)
+            right = right + ((fmix32((left + np.uint64(fk[r + 1])) & _M32) * ub) >> np.uint64(32))
+            right = np.where(right >= ub, right - ub, right)
+        w = (right << np.uint64(ka)) | left
         v[todo] = w
         todo[todo] = w >= n_pos
     return v < n_sel
@@ -147,7 +145,7 @@ def sample(items, pos_col, n_sel, p, seed, step, n_cols):
         lane = np.arange(64, dtype=np.uint64)
         rnd = 0
         while active.size:
-            bits = philox_u64(active.astype(np.uint64)[:, None], np.uint64(rnd * 64) + lane[None, :], np.uint64(0x5A4D504C), np.uint64(0), k0, k1)
+            bits = philox_u64(active.astype(np.uint64)[:, None] ^ np.uint64(k1), np.uint64(rnd * 64) + lane[None, :], k0)
             u = ((bits >> np.uint64(11)).astype(np.float64) + 0.5) * 2.0 ** -53
             with np.errstate(invalid="ignore"):
                 g = np.floor(det_log(u) * inv)
