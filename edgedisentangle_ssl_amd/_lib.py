@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libdisgat_hip.so")
 SOURCES = ["api_common.hip", "edge_fwd.hip", "aux_score.hip", "edge_bwd.hip", "gemm_split.hip", "gemm_planes.hip", "linear_skinny.hip",
-           "optim.hip", "pair_sample.hip"]
+           "optim.hip", "pair_sample.hip", "seg_tables.hip"]
 ARCH = "gfx950"
 ABI_VERSION = 4         # csrc/api_common.hip: bumped whenever a launcher's argument list changes (round 3: dropout seed
                         # counter, padding labels / items, score-gradient strides, amax outputs, plane outputs; round 4: pair sampler)
@@ -105,6 +105,7 @@ _SIGS = {
     "disgat_seg_grad_hx": (_c.c_int, [_c.c_int, _P, _c.c_int, _P, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int,
                                       _c.c_int, _P, _c.c_int, _P, _c.c_int, _c.c_int, _P, _P]),
     "disgat_seg_combine": (_c.c_int, [_P, _P, _c.c_int, _c.c_int, _P, _P, _c.c_int, _c.c_int, _P, _P]),
+    "disgat_seg_tables": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int, _c.c_int, _P, _P, _P, _P, _c.c_int, _P, _P, _c.c_int, _P, _P]),
     "disgat_gemm_split": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _P, _P, _P, _c.c_int64, _c.c_int64, _P, _c.c_int64,
                                      _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_float,
                                      _c.c_int, _P]),

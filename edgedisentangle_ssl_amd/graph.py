@@ -23,7 +23,7 @@ import torch
 
 
 class WorkItems:
-    __slots__ = ("items", "n_items", "split_rows", "split_ptr", "n_split", "n_slots", "chunk")
+    __slots__ = ("items", "n_items", "split_rows", "split_ptr", "n_split", "n_slots", "chunk", "totals")
 
 
 def build_items(ptr, chunk):

@@ -192,58 +192,34 @@ def _segments(keys, n_keys, chunk):
 
 
 def _segments_static(keys, n_keys, is_sorted, chunk):
-    """_segments() for the fixed-capacity lists of captured steps (sampling.StaticSampler): no size is read back and every
-    shape is fixed.  Keys longer than `chunk` entries are cut into near-equal slices exactly as build_items() cuts them,
-    but the item table has a fixed CAPACITY - n_keys + C // chunk bounds sum_k max(1, ceil(deg_k / chunk)) - and the
-    entries past the real count are padding (key -1: the kernels skip them), likewise the split-key table
-    (at most C // chunk keys are longer than chunk).  Items stay in key order."""
+    """_segments() for the fixed-capacity lists of captured steps (sampling.PairSampler.sample_static): no size is read back
+    and every shape is fixed.  Keys longer than `chunk` entries are cut into near-equal slices exactly as build_items() cuts
+    them, but the item table has a fixed CAPACITY - n_keys + C // chunk bounds sum_k max(1, ceil(deg_k / chunk)) - and the
+    entries past the real count are padding (key -1: the kernels skip them), likewise the split-key table (at most
+    C // chunk keys are longer than chunk).  Items stay in key order.  Three launches of this library
+    (disgat_seg_tables: csrc/seg_tables.hip) behind the column side's sort."""
     from .graph import WorkItems
     dev = keys.device
     c_len = int(keys.numel())
-    if is_sorted:
-        perm = perm32 = None
-    else:
-        perm = torch.sort(keys.to(torch.int32) if n_keys < 2 ** 31 else keys, stable=True).indices
-        keys = keys[perm]
-        perm32 = perm.to(torch.int32)
-    ptr = torch.searchsorted(keys, torch.arange(n_keys + 1, device=dev, dtype=keys.dtype))
+    perm = None if is_sorted else torch.sort(keys.to(torch.int32) if n_keys < 2 ** 31 else keys, stable=True).indices
+    slices = DETERMINISTIC and chunk < c_len
+    eff = chunk if slices else max(chunk, c_len, 1)              # no slices: one item per key
+    cap = n_keys + c_len // eff
+    n_split_cap = max(1, c_len // eff)
+    i32 = dict(dtype=torch.int32, device=dev)
+    ptr, key_off = torch.empty(n_keys + 1, **i32), torch.empty(2 * n_keys, **i32)
+    perm32 = None if perm is None else torch.empty(c_len, **i32)
     wi = WorkItems()
     wi.chunk = chunk
-    if not DETERMINISTIC or chunk >= c_len:          # no slices: one item per key
-        p32 = ptr.to(torch.int32)
-        wi.items = torch.stack([torch.arange(n_keys, device=dev, dtype=torch.int32), p32[:-1], p32[1:],
-                                torch.full((n_keys,), -1, dtype=torch.int32, device=dev)], 1).contiguous()
-        wi.n_items = int(n_keys)
-        wi.n_split = wi.n_slots = 0
-        wi.split_rows = wi.split_ptr = torch.zeros(1, dtype=torch.int32, device=dev)
-        return wi, perm, perm32
-    deg = ptr[1:] - ptr[:-1]
-    nchunk = torch.clamp((deg + chunk - 1) // chunk, min=1)
-    cum = torch.cumsum(nchunk, 0)
-    cap = n_keys + c_len // chunk
-    i = torch.arange(cap, device=dev, dtype=torch.int64)
-    valid = i < cum[-1]
-    key = torch.searchsorted(cum, i, right=True).clamp_(max=n_keys - 1)
-    nck, dk = nchunk[key], deg[key]
-    j = i - (cum[key] - nck)
-    size, rem = dk // nck, dk % nck
-    begin = ptr[:-1][key] + j * size + torch.minimum(j, rem)
-    end = begin + size + (j < rem).to(torch.int64)
-    split_item = valid & (nck > 1)
-    slot = torch.where(split_item, torch.cumsum(split_item.to(torch.int64), 0) - 1, torch.full_like(i, -1))
-    wi.items = torch.stack([torch.where(valid, key, torch.full_like(key, -1)), begin, end, slot], 1).to(torch.int32).contiguous()
+    wi.items = torch.empty((cap, 4), **i32)
+    wi.split_rows, wi.split_ptr = torch.empty(n_split_cap, **i32), torch.empty(n_split_cap + 1, **i32)
+    wi.totals = torch.empty(4, **i32)                            # items, split keys, slots actually in use (device)
+    _lib.call("disgat_seg_tables", keys.data_ptr(), ops._ptr(perm), c_len, int(n_keys), int(eff), ptr.data_ptr(), key_off.data_ptr(),
+              ops._ptr(perm32), wi.items.data_ptr(), cap, wi.split_rows.data_ptr(), wi.split_ptr.data_ptr(), n_split_cap,
+              wi.totals.data_ptr(), ops._stream())
     wi.n_items = int(cap)
-    # split-key table: key ids in key order, -1 padded; split_ptr = exclusive prefix of the split keys' slice counts
-    n_split_cap = max(1, c_len // chunk)
-    is_split = nchunk > 1
-    rank = torch.cumsum(is_split.to(torch.int64), 0) - 1
-    where = torch.where(is_split, rank, torch.full_like(rank, n_split_cap))
-    rows = torch.full((n_split_cap + 1,), -1, dtype=torch.int64, device=dev).scatter_(0, where, torch.arange(n_keys, device=dev))
-    cnt = torch.zeros(n_split_cap + 2, dtype=torch.int64, device=dev).scatter_(0, where + 1, nchunk)   # last entry: the unsplit keys' dump
-    wi.split_rows = rows[:n_split_cap].to(torch.int32).contiguous()
-    wi.split_ptr = torch.cumsum(cnt[: n_split_cap + 1], 0).to(torch.int32).contiguous()
-    wi.n_split = int(n_split_cap)
-    wi.n_slots = int(2 * (c_len // chunk) + 2)        # sum over keys longer than chunk of ceil(deg / chunk) <= 2 C / chunk
+    wi.n_split = int(n_split_cap) if slices else 0
+    wi.n_slots = int(2 * (c_len // chunk) + 2) if slices else 0   # sum over keys longer than chunk of ceil(deg / chunk) <= 2 C / chunk
     return wi, perm, perm32
 
 

@@ -192,6 +192,19 @@ int disgat_seg_combine(const int32_t* split_keys, const int32_t* split_ptr, int 
                        const float* part, float* gkey, int ld_gkey, int accumulate, float* amax_out,
                        disgat_stream_t stream);
 
+/* Work-item tables of the three segment launchers above for a key-sorted list of FIXED capacity C (a pair list of a step
+ * captured in a HIP graph: nothing is read back, every table has a fixed shape, unused tails are padding).
+ *   keys [C] int64 (node ids < n_keys), sorted - or sorted through perm [C] int64 (the sort's indices: list position m holds
+ *   keys[perm[m]]); perm32 [C] then receives perm as int32 (both NULL for a sorted list).
+ *   ptr [n_keys + 1], key_off [2 n_keys]: scratch (ptr[k] = first list position of key k is also the CSR pointer of the list).
+ *   items [cap_items][4], cap_items >= n_keys + C / chunk: {key, m_begin, m_end, slot} in key order, a key longer than chunk
+ *   cut into ceil(deg / chunk) near-equal slices with consecutive slots; {-1, 0, 0, -1} past the last item.
+ *   split_rows [n_split_cap], split_ptr [n_split_cap + 1], n_split_cap >= max(1, C / chunk): disgat_seg_combine's tables
+ *   (-1 / total padded).  totals [4] (device): items, split keys, slots in use. */
+int disgat_seg_tables(const int64_t* keys, const int64_t* perm, int64_t C, int n_keys, int chunk, int32_t* ptr,
+                      int32_t* key_off, int32_t* perm32, int32_t* items, int cap_items, int32_t* split_rows,
+                      int32_t* split_ptr, int n_split_cap, int32_t* totals, disgat_stream_t stream);
+
 /* ---- dense contractions --------------------------------------------------------------------- */
 
 /* fp32-accurate GEMM on the bf16 matrix cores (split-bf16, 6 partial products; terms = 3 keeps 3):

@@ -38,7 +38,7 @@ for n, (tr, a) in kept.items():
     kern = [e for e in ev if e.device_type == torch.autograd.DeviceType.CUDA]
     tot = sum(e.count for e in kern)
     print(f"\n== {n}: {tot} device launches per step")
-    for e in sorted(kern, key=lambda e: -e.count)[:14]:
+    for e in sorted(kern, key=lambda e: -e.count)[:int(os.environ.get('OP_COUNT_TOP', 14))]:
         print(f"   {e.count:4d}  {e.key[:110]}")
     ops = [e for e in ev if e.device_type != torch.autograd.DeviceType.CUDA and e.key.startswith("aten::")]
     print("   aten ops:", ", ".join(f"{e.key[6:]} x{e.count}" for e in sorted(ops, key=lambda e: -e.count)[:28]))
