@@ -28,10 +28,12 @@ struct AuxArgs {
   const float* a;
   float* out;
   uint32_t* sign;   // att 3, optional: [M][64] sign words for the backward pass (disgat_common.h)
+  int batches;      // att 3 / 4: 64-pair batches per wave (1 .. AUX3_BATCHES)
 };
 
 // 64-pair batches one wave walks (its `a` vector and a row operand spanning batches are loaded once): same-box T_iter
-// at C4 with 1 / 2 / 4 / 8: 6363 / 6370 / 6397 / 6400 GB/s
+// at C4 with 1 / 2 / 4 / 8: 6363 / 6370 / 6397 / 6400 GB/s.  Lists too short to give every SIMD a few waves that way walk
+// fewer (AuxArgs::batches: a 45 K-pair Cora list is 176 waves of 256 pairs, one fifth of the chip's SIMDs, or 707 of 64)
 #ifndef AUX3_BATCHES
 #define AUX3_BATCHES 4
 #endif
@@ -43,7 +45,7 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void aux_att3_kernel(const AuxArgs
   constexpr int G = 1 << GL;
   constexpr int FQ = QN * G * 4;
   const int lane = threadIdx.x & 63;
-  const int64_t mw = ((int64_t)blockIdx.x * DISGAT_WAVES_PER_BLOCK + (threadIdx.x >> 6)) * (64 * AUX3_BATCHES);
+  const int64_t mw = ((int64_t)blockIdx.x * DISGAT_WAVES_PER_BLOCK + (threadIdx.x >> 6)) * (64 * A.batches);
   if (mw >= A.M) return;
   const int myh = lane >> GL;
   const bool active = (myh >= A.h_lo) && (myh < A.h_hi);
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void aux_att3_kernel(const AuxArgs
     for (int t = 0; t < KEEP; ++t) keep[t] = (mine && slot == t) ? acc : keep[t];
   };
 
-  for (int b = 0; b < AUX3_BATCHES; ++b) {
+  for (int b = 0; b < A.batches; ++b) {
     m0 = mw + (int64_t)b * 64;
     if (m0 >= A.M) break;
     cnt = (int)min((int64_t)64, A.M - m0);
@@ -349,9 +351,10 @@ extern "C" int disgat_aux_score(int att, const int64_t* pair_rows, const int64_t
   DISGAT_REQUIRE(h_lo >= 0 && h_hi <= H, "aux_score: head range [%d,%d) outside [0,%d)", h_lo, h_hi, H);
   DISGAT_REQUIRE(pair_rows && pair_cols && rowop && out, "aux_score: null pointer");
   AuxArgs A{pair_rows, pair_cols, M, N, F_in, h_lo, h_hi, x, ldx, rowop, ld_row, colop, ld_col, a, out,
-            att == 3 ? sign_bits : nullptr};
+            att == 3 ? sign_bits : nullptr, AUX3_BATCHES};
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const int64_t per_wave = (att == 3 || att == 4) ? 64 * AUX3_BATCHES : 64;
+  while (A.batches > 1 && M < (int64_t)64 * A.batches * 8192) --A.batches;      // short lists: more, shorter waves
+  const int64_t per_wave = (att == 3 || att == 4) ? 64 * A.batches : 64;
   const int64_t waves = (M + per_wave - 1) / per_wave;
   const int64_t grid64 = (waves + DISGAT_WAVES_PER_BLOCK - 1) / DISGAT_WAVES_PER_BLOCK;
   DISGAT_REQUIRE(grid64 < (int64_t)1 << 31, "aux_score: M too large for one launch");

@@ -113,3 +113,43 @@ def test_main_flow_trains_captured(golden_dir, gnn, att):
     # different dropout masks and pair lists, same distribution: the two runs stay close
     for k in ("loss_train", "loss_head_diversity"):
         assert abs(hist[-1][k] - ref[-1][k]) < 0.25 * abs(ref[-1][k]) + 0.05, (k, hist[-1][k], ref[-1][k])
+
+
+def test_graphs_die_with_their_trainers_by_reference_count(golden_dir):
+    """trainer and StaticStep used to reference each other, so HIP graphs were freed only by the cyclic
+    collector, at a time nobody chose - once inside a later capture, where destroying a graph aborts the process.  Now the
+    step holds its trainer weakly: dropping the trainers frees steps and graphs on the spot (checked with the collector
+    OFF), Trainer.close() does the same explicitly, and a second trainer set captures and replays with the collector
+    running at every allocation (gc.set_threshold(1))."""
+    import gc
+    import weakref
+    dev = torch.device("cuda")
+    data, labels, ct, trs = _trainers(golden_dir, dev, seed=21)
+    ct.train_step_captured(data, labels)
+    for tr, extra in ((trs[0], (data[1],)), (trs[1], ()), (trs[2], ())):
+        tr.train_step_captured(data, *extra)
+    steps = [weakref.ref(t.static_step()) for t in [ct] + trs]
+    graphs = [weakref.ref(t.static_step().graph) for t in [ct] + trs]
+    owners = [weakref.ref(t) for t in [ct] + trs]
+    assert all(g() is not None for g in graphs)
+    gc.collect()
+    gc.disable()
+    try:
+        trs[2].close()                                  # explicit: the graph goes, the trainer stays usable
+        assert graphs[3]() is None and steps[3]() is None and owners[3]() is not None
+        del ct, trs, tr
+        assert all(r() is None for r in steps + graphs + owners), [r() for r in steps + graphs + owners]
+    finally:
+        gc.enable()
+    old = gc.get_threshold()
+    gc.set_threshold(1)
+    try:
+        data2, labels2, ct2, trs2 = _trainers(golden_dir, dev, seed=22)
+        for _ in range(2):
+            ct2.train_step_captured(data2, labels2)
+            for tr, extra in ((trs2[0], (data2[1],)), (trs2[1], ()), (trs2[2], ())):
+                lg = tr.train_step_captured(data2, *extra)
+        torch.cuda.synchronize()
+        assert all(torch.isfinite(v).all() for v in lg.values())
+    finally:
+        gc.set_threshold(*old)
