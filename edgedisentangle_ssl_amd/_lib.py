@@ -104,6 +104,7 @@ _SIGS = {
                                         _P, _c.c_int, _P, _P, _c.c_int, _P, _c.c_int, _c.c_int, _P, _P, _P]),
     "disgat_seg_grad_hx": (_c.c_int, [_c.c_int, _P, _c.c_int, _P, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int,
                                       _c.c_int, _P, _c.c_int, _P, _c.c_int, _c.c_int, _P, _P]),
+    "disgat_seg_sum": (_c.c_int, [_P, _c.c_int, _P, _P, _c.c_int64, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _P, _c.c_int, _c.c_int, _P, _P]),
     "disgat_seg_combine": (_c.c_int, [_P, _P, _c.c_int, _c.c_int, _P, _P, _c.c_int, _c.c_int, _P, _P]),
     "disgat_seg_tables": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int, _c.c_int, _P, _P, _P, _P, _c.c_int, _P, _P, _c.c_int, _P, _P]),
     "disgat_gemm_split": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _P, _P, _P, _c.c_int64, _c.c_int64, _P, _c.c_int64,

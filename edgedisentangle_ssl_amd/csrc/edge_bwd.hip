@@ -518,6 +518,45 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void seg_grad_hx_col_kernel(const 
     if (i * 256 + xoff < A.F) out4(op + i * 256, acc[i], slot >= 0 && !to_part, A.accumulate != 0 && !to_part);
 }
 
+// att 1 (e = s1[row] + s2[col], layers.py:349-353): the score operands' gradients are plain segment sums of the score
+// gradients, gkey[key][h] = sum over the key's list positions of g[h][perm(m)].  One wave per item, lane = (position slot,
+// head); every lane adds its positions in list order, the slots of a head are combined by a symmetric butterfly: a fixed
+// summation order, no float atomics (the reference's index_add_-style autograd is neither).
+struct SumArgs {
+  const int4* items;
+  int n_items;
+  const int32_t* perm;
+  const float* g;
+  int64_t g_stride, g_pos_stride;
+  int h_lo, h_hi, H;
+  float* gkey;
+  int ld;
+  int accumulate;
+  float* part;
+};
+__global__ __launch_bounds__(DISGAT_BLOCK) void seg_sum_kernel(const SumArgs A) {
+  const int lane = threadIdx.x & 63;
+  const int item = blockIdx.x * DISGAT_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+  if (item >= A.n_items) return;
+  const int4 it = A.items[item];
+  const int key = rfl(it.x), mb = rfl(it.y), me = rfl(it.z), slot = rfl(it.w);
+  if (key < 0) return;              // padding item of a fixed-capacity item table (captured steps)
+  const int h = lane & (A.H - 1), p = lane / A.H, P = 64 / A.H;
+  const bool hact = h >= A.h_lo && h < A.h_hi;
+  float acc = 0.f;
+  if (hact)
+    for (int m = mb + p; m < me; m += P) {
+      const int64_t pos = A.perm ? A.perm[m] : m;
+      acc += A.g[(int64_t)h * A.g_stride + pos * A.g_pos_stride];
+    }
+  for (int o = 32; o >= A.H; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (lane < A.ld) {                // lanes H .. ld-1: the zero padding of rows narrower than 4 floats
+    float* out = seg_out_row(A.gkey, A.part, A.ld, key, slot) + lane;
+    const float v = lane < A.H ? acc : 0.f;
+    *out = (A.accumulate && !(slot >= 0 && A.part != nullptr)) ? *out + v : v;
+  }
+}
+
 // gkey[key][0:width] (+)= sum of the key's partial records, in slice order: one block per split key.
 __global__ __launch_bounds__(256) void seg_combine_kernel(const int32_t* __restrict__ split_keys, const int32_t* __restrict__ split_ptr,
                                                           int width, const float* __restrict__ part, int ld, float* __restrict__ gkey,
@@ -717,6 +756,21 @@ extern "C" int disgat_seg_grad_hx(int col_mode, const int32_t* items, int n_item
   const int xn = (F + 255) / 256;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   return col_mode ? launch_hx<true>(A, hl, xn, s) : launch_hx<false>(A, hl, xn, s);
+}
+
+extern "C" int disgat_seg_sum(const int32_t* items, int n_items, const int32_t* perm, const float* g, int64_t g_stride,
+                              int64_t g_pos_stride, int h_lo, int h_hi, int H, float* gkey, int ld_gkey, int accumulate,
+                              float* part, disgat_stream_t stream) {
+  using namespace disgat;
+  if (n_items == 0) return 0;
+  const int hl = ilog2_exact(H);
+  DISGAT_REQUIRE(hl >= 1 && hl <= 4, "seg_sum: H=%d must be a power of two in [2,16]", H);
+  DISGAT_REQUIRE(items && g && gkey && h_lo >= 0 && h_hi <= H, "seg_sum: null pointer / head range");
+  DISGAT_REQUIRE(ld_gkey >= H && ld_gkey <= 64 && ld_gkey % 4 == 0, "seg_sum: row stride %d (H <= stride <= 64, a multiple of 4)", ld_gkey);
+  SumArgs A{reinterpret_cast<const int4*>(items), n_items, perm, g, g_stride, g_pos_stride, h_lo, h_hi, H, gkey, ld_gkey, accumulate, part};
+  const dim3 grid((n_items + DISGAT_WAVES_PER_BLOCK - 1) / DISGAT_WAVES_PER_BLOCK), block(DISGAT_BLOCK);
+  hipLaunchKernelGGL(seg_sum_kernel, grid, block, 0, reinterpret_cast<hipStream_t>(stream), A);
+  return check_launch("seg_sum_kernel");
 }
 
 extern "C" int disgat_seg_combine(const int32_t* split_keys, const int32_t* split_ptr, int n_split, int width,

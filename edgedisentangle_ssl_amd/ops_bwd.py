@@ -90,6 +90,18 @@ def _seg_hx(col_mode, wi, other, perm, coef, lo, hi, H, f, otherop, gkey, accumu
     _combine(wi, part, gkey, f if col_mode else H * f, accumulate)
 
 
+def _seg_sum(wi, perm, g, lo, hi, H, n_keys):
+    """att 1: [n_keys, H] segment sums of the score gradients g [H, M] over a key-sorted list (fixed order, no atomics)."""
+    g, g_hs, g_ps = _g_strides(g, H)
+    ld = (H + 3) // 4 * 4
+    gkey = _keybuf((n_keys, ld), g.device, wi)
+    part = _part(wi, gkey)
+    _lib.call("disgat_seg_sum", wi.items.data_ptr(), wi.n_items, ops._ptr(perm), g.data_ptr(), g_hs, g_ps, lo, hi, H,
+              gkey.data_ptr(), ld, 0, ops._ptr(part), ops._stream())
+    _combine(wi, part, gkey, ld, False)
+    return gkey if ld == H else gkey[:, :H]
+
+
 def edge_backward(ctx, gz, ge, want_ge=False):
     """Returns (g_x, g_rowop, g_colop, g_a, None, ge_tot or None): the last entry is the total gradient of the raw
     scores [H,E] (= the gradient of an additive e_in input), only when want_ge."""
@@ -112,10 +124,15 @@ def edge_backward(ctx, gz, ge, want_ge=False):
     g_x = g_row = g_col = g_a = None
     t = twi = None
     sign = getattr(ctx, "sign", None)
-    if need_x or (att == 4 and need_col) or (att == 3 and (need_col or (need_a and sign is not None))):
+    if need_x or (att in (1, 4) and need_col) or (att == 3 and (need_col or (need_a and sign is not None))):
         t = graph.transpose()
         twi = t.work_items(chunk)
-    if att == 1:
+    if att == 1 and DETERMINISTIC:                      # gs1[r] = sum over the row's edges, gs2[c] = sum over the column's
+        if need_row:
+            g_row = _seg_sum(wi, None, ge_tot, 0, H, H, n)
+        if need_col:
+            g_col = _seg_sum(twi, t.eid, ge_tot, 0, H, H, colop.shape[0])
+    elif att == 1:
         if need_row:
             g_row = torch.zeros((n, H), dtype=torch.float32, device=dev).index_add_(0, graph.row, ge_tot.t())
         if need_col:
@@ -233,6 +250,15 @@ def aux_backward(ctx, gout):
     gout = gout.contiguous()
     rows, cols = pairs[0], pairs[1]
     g_x = g_row = g_col = g_a = None
+    if att == 1 and DETERMINISTIC:
+        chunk = ops.chunk_small(att, int(pairs.shape[1]), H)
+        if need_row:
+            wi, _perm, perm32 = _segments_of(pairs, 0, rowop.shape[0], chunk)
+            g_row = _seg_sum(wi, perm32, gout, lo, hi, H, rowop.shape[0])
+        if need_col:
+            wi, _perm, perm32 = _segments_of(pairs, 1, colop.shape[0], chunk)
+            g_col = _seg_sum(wi, perm32, gout, lo, hi, H, colop.shape[0])
+        return g_x, g_row, g_col, g_a, None, None
     if att == 1:
         gsub = gout[lo:hi].t()
         if need_row:

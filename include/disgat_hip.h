@@ -182,6 +182,14 @@ int disgat_seg_grad_hx(int col_mode, const int32_t* items, int n_items, const in
                        int F, const float* otherop, int ld_other, float* gkey, int ld_gkey, int accumulate,
                        float* part, disgat_stream_t stream);
 
+/* att 1 (e = s1[row][h] + s2[col][h], layers.py:349-353): the gradient of a score operand is the segment sum of the score
+ * gradients, gkey[key][h] (+)= sum over the key's list positions m of g[h * g_stride + perm(m) * g_pos_stride] for h in
+ * [h_lo, h_hi) (0 for the other heads).  Items / perm / part / accumulate as in the launchers above; ld_gkey = H rounded up to
+ * a multiple of 4 (columns H .. ld_gkey-1 are written as zeros).  Fixed summation order: no float atomics. */
+int disgat_seg_sum(const int32_t* items, int n_items, const int32_t* perm, const float* g, int64_t g_stride,
+                   int64_t g_pos_stride, int h_lo, int h_hi, int H, float* gkey, int ld_gkey, int accumulate,
+                   float* part, disgat_stream_t stream);
+
 /* Split keys (hub rows / columns cut into several work items, slot >= 0): when `part` ([n_slots][ld_gkey] floats) is
  * given to the three segment launchers above, every slice stores its partial result in part[slot] instead of adding
  * to gkey with float atomics, and this launcher then forms gkey[key][0:width] (+)= sum of the key's slices in slice

@@ -200,3 +200,33 @@ def test_att3_gradient_at_the_leaky_relu_kink(dev, sign, monkeypatch):
     ((h_o * w.cpu().double()).sum() + (e_o * e_o).sum() + sum((t * t).sum() for t in au_o)).backward()
     for k, v in lay_d.named_parameters():
         close(v.grad, p[k].grad.float().numpy(), tol=GTOL, what=f"kink grad {k} (sign={sign})")
+
+
+@pytest.mark.parametrize("att", [1, 2, 3])
+def test_gradients_repeat_bit_for_bit(golden_dir, dev, att, monkeypatch):
+    """ops_bwd.DETERMINISTIC: no float atomics anywhere in the backward - hub rows / columns split across work items are
+    combined in slice order, and att 1's score-operand gradients are fixed-order segment sums (disgat_seg_sum), not
+    index_add_.  Two backward passes over the same inputs (chameleon: hub rows of several hundred edges, small slices) give
+    the same bits in every encoder gradient, for the edge list and the pair lists."""
+    from edgedisentangle_ssl_amd import ops, ops_bwd
+    from test_gpu_parity import real_inputs
+    assert ops_bwd.DETERMINISTIC
+    monkeypatch.setattr(ops, "CHUNK", {1: 32, 2: 32, 3: 32, 4: 32})
+    x, adj, n, ei, sup, ho, he = real_inputs(golden_dir, "chameleon", dev)
+    sup, ho, he = ([t.to(dev) for t in lst] for lst in (sup, ho, he))
+    a, enc, _ = build("AT", att, 8, 64, x.shape[1], 300 + att, dev)
+    sup_t, dis_t, dif_t = _trainers(a, enc, 300 + att, dev)
+    data = (x, adj)
+    runs = []
+    for _rep in range(2):
+        grads = {}
+        for name, fn in (("sup", lambda: sup_t.loss(data, sup[1], [sup[0]])),
+                         ("dis", lambda: dis_t.loss(data, [ho[1], he[1]], [ho[0], he[0]])), ("dif", lambda: dif_t.loss(data))):
+            _zero(enc)
+            fn().backward()
+            ops_bwd.clear_segment_cache()
+            grads.update({f"{name}.{k}": p.grad.clone() for k, p in enc.named_parameters() if p.grad is not None})
+        runs.append(grads)
+    assert runs[0].keys() == runs[1].keys() and len(runs[0]) > 10
+    for k in runs[0]:
+        assert torch.equal(runs[0][k], runs[1][k]), k
