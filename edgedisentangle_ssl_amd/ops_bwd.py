@@ -339,19 +339,21 @@ def layer_backward_u(ctx, gz, ge, gaux):
             if go is not None and sg is not None]          # [H, M], possibly [M, H]-backed (_g_strides)
     g_a = None
 
-    def dense_side(x_in, w, u, am, need_in, need_w, u_amax, add_to=None):
+    def dense_side(x_in, w, u, am, need_in, need_w, u_amax, add_to=None, with_a=True):
         """(grad x_in, grad w, this side's share of grad a) from u [rows, H*F_out]; u_amax: the bound on |u| the segment
         passes kept while storing it (max over everything they stored, so >= max |u|), or None; add_to: another
-        contribution to grad x_in, added in the GEMM's epilogue."""
+        contribution to grad x_in, added in the GEMM's epilogue; with_a = False: no weight-gradient GEMM for grad a's sake
+        (a second call will run it)."""
         nonlocal g_a
         if u is None:
             return add_to, None
+        want_a = need_a and with_a
         with torch.no_grad():
             g_in, G = ops_gemm.linear_backward(x_in.detach(), (w.detach() * a.detach()) if need_in else w.detach(), u, am,
-                                               need_in, need_w or need_a, g_amax=u_amax, ga_init=add_to if need_in else None)
+                                               need_in, need_w or want_a, g_amax=u_amax, ga_init=add_to if need_in else None)
             g_w = None
             if G is not None:
-                if need_a:
+                if want_a:
                     ga = (w.detach() * G).sum(0)
                     g_a = ga if g_a is None else g_a + ga
                 if need_w:
@@ -386,10 +388,16 @@ def layer_backward_u(ctx, gz, ge, gaux):
     # three contributions to ONE gradient: the second GEMM adds the first's result in its epilogue and the aggregation pass
     # accumulates into that buffer, instead of autograd summing three [N, F_in] tensors afterwards
     same_pq = x_p is x_q and need_xp and need_xq and g_xp is not None
-    g_xq, g_wb = dense_side(x_q, w_bot, u, am_q, need_xq, need_wb, b_col, add_to=g_xp if same_pq else None)
+    # sharded: x_q is the gathered table and its gradient must travel back to the rows' owners (reduce-scatter).  Its data
+    # gradient comes first, the aggregation's share is added, the reduce-scatter goes on the links (parallel.start_adjoint)
+    # and the weight-gradient GEMM of the same operand runs under it; _AllGatherRows.backward then only collects the result
+    early = need_xq and u is not None and getattr(x_q, "_disgat_gather", None) is not None
+    if early:
+        g_xq, _ = dense_side(x_q, w_bot, u, am_q, True, False, b_col, add_to=g_xp if same_pq else None, with_a=False)
+    else:
+        g_xq, g_wb = dense_side(x_q, w_bot, u, am_q, need_xq, need_wb, b_col, add_to=g_xp if same_pq else None)
     if same_pq:
         g_xp = None
-    u = None
     g_x = None
     if have_edge and need_x:
         tgt = g_xq if (x is x_q and g_xq is not None and g_xq.shape == x.shape and g_xq.stride(0) == f_in) else None
@@ -398,6 +406,12 @@ def layer_backward_u(ctx, gz, ge, gaux):
         else:
             g_x = _keybuf(tuple(x.shape), dev, twi, x.stride(0) != f_in)
             _seg_hx(1, twi, t.col, t.eid, beta, 0, H, H, f_in, gz.view(n, H * f_in), g_x, False)
+    if early:
+        from . import parallel
+        if g_x is None:                  # g_xq is the whole gradient of the table (the aggregation added its share above)
+            parallel.start_adjoint(x_q, g_xq)
+        _, g_wb = dense_side(x_q, w_bot, u, am_q, False, need_wb, b_col)
+    u = None
     return (g_x, None, None, g_a if need_a else None, None) + (None,) * n_lists + (g_xp, g_wt, g_xq, g_wb)
 
 

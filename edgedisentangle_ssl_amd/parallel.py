@@ -79,10 +79,12 @@ def exchange_slices():
     return max(1, int(os.environ.get("DISGAT_EXCHANGE_SLICES", "4")))
 
 
-_PENDING = {}       # data_ptr of an x_all still being filled -> its PendingGather
-
-
 class PendingGather:
+    """The slices of one gathered table still on the links.  It hangs on the table itself (attribute `_disgat_pending`,
+    set by _gather_rows) - no registry keyed by an address that a later tensor could inherit; it holds the table's storage
+    through a raw alias only, so table and gather form no reference cycle and an abandoned gather (an exception between
+    its start and wait_all) dies with the table."""
+
     def __init__(self, x_local, counts, group, n_slices):
         world, rank = len(counts), dist.get_rank(group)
         self.counts, self.rank, self.group = counts, rank, group
@@ -110,13 +112,21 @@ class PendingGather:
             work = dist.all_gather_into_tensor(tmp, inp.contiguous(), group=group, async_op=True)
             self.slices.append((work, tmp, ms, lo, sz))
         self.next = 0
-        _PENDING[self.x_all.data_ptr()] = self
+        self.raw = self.x_all            # fills go through this alias (replaced by x_all.data once autograd owns x_all)
+
+    @property
+    def done(self):
+        return self.next >= len(self.slices)
+
+    def release(self):
+        """Called once _AllGatherRows.forward has returned x_all: keep the storage, not the autograd output."""
+        self.raw = self.x_all.data
+        self.x_all = None
 
     def wait_next(self):
         """Wait (stream-level) for the next slice and copy the peers' rows into place.  Returns the global row ranges
         [(lo, hi), ...] that became valid, or None when nothing is pending any more."""
         if self.next >= len(self.slices):
-            _PENDING.pop(self.x_all.data_ptr(), None)
             return None
         work, tmp, ms, lo, sz = self.slices[self.next]
         self.slices[self.next] = None
@@ -129,10 +139,8 @@ class PendingGather:
             g0 = self.offsets[r] + l
             # a raw fill of the buffer, never an autograd op: by now x_all is the OUTPUT of _AllGatherRows, and a tracked
             # in-place copy would cut these rows out of its backward (their gradient must reach the reduce-scatter)
-            self.x_all.data[g0: g0 + n] = tmp[r * ms: r * ms + n]
+            self.raw[g0: g0 + n] = tmp[r * ms: r * ms + n]
             ranges.append((g0, g0 + n))
-        if self.next >= len(self.slices):
-            _PENDING.pop(self.x_all.data_ptr(), None)
         return ranges
 
     def wait_all(self):
@@ -142,7 +150,8 @@ class PendingGather:
 
 def pending_of(x_all):
     """The PendingGather still filling `x_all`, or None (unsharded / complete / halo table)."""
-    return _PENDING.get(x_all.data_ptr()) if torch.is_tensor(x_all) else None
+    pend = getattr(x_all, "_disgat_pending", None) if torch.is_tensor(x_all) else None
+    return pend if (pend is not None and not pend.done) else None
 
 
 def finish(x_all):
@@ -153,28 +162,20 @@ def finish(x_all):
     return x_all
 
 
-class _AllGatherRows(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, counts, group, n_slices=1, leave_pending=False):
-        ctx.counts, ctx.group = counts, group
-        pend = PendingGather(x, counts, group, n_slices)
-        if not leave_pending:
-            pend.wait_all()
-        return pend.x_all
+class GatherAdjoint:
+    """Adjoint of the all-gather, in flight: every rank holds a gradient for ALL rows; the owner of a row range needs their
+    sum over ranks = one reduce-scatter (each rank receives 1/G of what an all-reduce would move), ragged ranges padded to
+    the longest.  Issued asynchronously; result() makes the compute stream (not the host) wait for it."""
 
-    @staticmethod
-    def backward(ctx, g):
-        """Adjoint of the all-gather: every rank holds a gradient for ALL rows; the owner of a row range needs their
-        sum over ranks = one reduce-scatter (each rank receives 1/G of what an all-reduce would move), ragged ranges
-        padded to the longest; asynchronous, the compute stream (not the host) waits for it."""
-        counts, group = ctx.counts, ctx.group
-        rank = dist.get_rank(group)
-        world = len(counts)
+    def __init__(self, g, counts, group):
+        rank, world = dist.get_rank(group), len(counts)
+        self.src_version = g._version
         g = g.contiguous()
         if len(set(counts)) == 1:
-            out = g.new_empty((counts[0],) + tuple(g.shape[1:]))
-            dist.reduce_scatter_tensor(out, g, group=group, async_op=True).wait()
-            return out, None, None, None, None
+            self.out = g.new_empty((counts[0],) + tuple(g.shape[1:]))
+            self.keep = g
+            self.work = dist.reduce_scatter_tensor(self.out, g, group=group, async_op=True)
+            return
         mx = max(counts)                          # ragged (nnz-balanced) ranges: pad every range to the longest
         pad = g.new_zeros((world, mx) + tuple(g.shape[1:]))
         off = 0
@@ -182,8 +183,64 @@ class _AllGatherRows(torch.autograd.Function):
             pad[r, :c] = g[off: off + c]
             off += c
         out = g.new_empty((mx,) + tuple(g.shape[1:]))
-        dist.reduce_scatter_tensor(out, pad.view((world * mx,) + tuple(g.shape[1:])), group=group, async_op=True).wait()
-        return out[: counts[rank]], None, None, None, None
+        self.keep = pad
+        self.work = dist.reduce_scatter_tensor(out, pad.view((world * mx,) + tuple(g.shape[1:])), group=group, async_op=True)
+        self.out = out[: counts[rank]]
+
+    def result(self):
+        self.work.wait()
+        self.keep = None
+        return self.out
+
+
+ADJOINT_EARLY_STARTS = 0        # how many adjoints were put on the links by their producer (tests read this)
+
+
+def start_adjoint(x_all, g):
+    """Called by the backward that has just finished g = d loss / d x_all (ops_bwd.layer_backward_u: the data-gradient GEMM
+    of the column-side score operand, plus the aggregation's share) BEFORE it goes on with work that does not touch g (its
+    weight-gradient GEMM): the reduce-scatter starts now and runs on the links under that work; _AllGatherRows.backward
+    picks the result up.  No-op for tensors that are not a gathered table."""
+    global ADJOINT_EARLY_STARTS
+    info = getattr(x_all, "_disgat_gather", None) if torch.is_tensor(x_all) else None
+    if info is None or g is None or tuple(g.shape) != tuple(x_all.shape):
+        return False
+    g._disgat_adjoint = GatherAdjoint(g, *info)
+    ADJOINT_EARLY_STARTS += 1
+    return True
+
+
+class _AllGatherRows(torch.autograd.Function):
+    _handoff = []           # forward -> _gather_rows: the PendingGather of the table just returned
+
+    @staticmethod
+    def forward(ctx, x, counts, group, n_slices=1, leave_pending=False):
+        ctx.counts, ctx.group = counts, group
+        pend = PendingGather(x, counts, group, n_slices)
+        if not leave_pending:
+            pend.wait_all()
+        _AllGatherRows._handoff.append(pend)
+        return pend.x_all
+
+    @staticmethod
+    def backward(ctx, g):
+        early = getattr(g, "_disgat_adjoint", None)
+        if early is not None and early.src_version == g._version:      # already on the links (start_adjoint)
+            g._disgat_adjoint = None
+            return early.result(), None, None, None, None
+        return GatherAdjoint(g, ctx.counts, ctx.group).result(), None, None, None, None
+
+
+def _gather_rows(x_local, counts, group, n_slices, leave_pending):
+    """_AllGatherRows.apply + what hangs on its output: the gather still pending (pending_of) and the marker that lets
+    the consumer's backward start the adjoint early (start_adjoint)."""
+    del _AllGatherRows._handoff[:]
+    x_all = _AllGatherRows.apply(x_local, counts, group, n_slices, leave_pending)
+    pend = _AllGatherRows._handoff.pop()
+    pend.release()
+    x_all._disgat_pending = None if pend.done else pend
+    x_all._disgat_gather = (counts, group)
+    return x_all
 
 
 class _ProjectGathered(torch.autograd.Function):
@@ -231,7 +288,7 @@ def all_gather_rows(x_local, graph):
     """[n_local,F] on every rank -> [n_global,F] (rank order = row order).  Identity when unsharded."""
     if not isinstance(graph, DistGraph) or graph.world == 1:
         return x_local
-    return _AllGatherRows.apply(x_local, graph.counts, graph.group, exchange_slices(), False)
+    return _gather_rows(x_local, graph.counts, graph.group, exchange_slices(), False)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -358,10 +415,10 @@ def exchange(x_local, graph, edge_only, pipelined=False):
         hit = graph.__dict__.get("_static_gather")
         if hit is not None and hit[0] == key:
             return hit[1], graph
-        x_all = _AllGatherRows.apply(x_local, graph.counts, graph.group, exchange_slices(), False)
+        x_all = _gather_rows(x_local, graph.counts, graph.group, exchange_slices(), False)
         graph._static_gather = (key, x_all.detach())
         return x_all, graph
-    return _AllGatherRows.apply(x_local, graph.counts, graph.group, exchange_slices(), bool(pipelined)), graph
+    return _gather_rows(x_local, graph.counts, graph.group, exchange_slices(), bool(pipelined)), graph
 
 
 _SEEN_FLAGS = {}

@@ -189,6 +189,10 @@ def _train_worker(rank, world, port, q, golden_dir):
         logs.update(sup_t.train_step((xl, dg)))
         logs.update(dis_t.train_step((xl, dg)))
         logs.update(dif_t.train_step((xl, dg)))
+        # the column-side score operand's backward put the gathered table's adjoint on the links itself, before its
+        # weight-gradient GEMM (ops_bwd.layer_backward_u -> parallel.start_adjoint): once per SSL step (layer 2; the features
+        # that enter layer 1 need no gradient, so nothing travels back there)
+        assert parallel.ADJOINT_EARLY_STARTS == 3, parallel.ADJOINT_EARLY_STARTS
         import random
         random.seed(7)                                      # the node split is drawn from `random`: same on every rank
         cls_t = ClsTrainer(a, enc, lab, 1.0)

@@ -32,7 +32,7 @@ x = ic.features(3, n, 16).to(dev)
 
 # all-gather of rows + its reduce-scatter adjoint (equal counts) through the autograd wrapper
 xl = x.clone().requires_grad_(True)
-xa = parallel._AllGatherRows.apply(xl, dg.counts, None)
+xa = parallel._gather_rows(xl, dg.counts, None, 1, False)
 assert torch.equal(xa.detach(), x)
 w = torch.arange(n, dtype=torch.float32, device=dev).unsqueeze(1)
 (xa * w).sum().backward()
@@ -43,7 +43,7 @@ from edgedisentangle_ssl_amd import ops_gemm
 xw = ic.features(5, n, 64).to(dev)
 w64 = (ic.features(6, 64, 256).to(dev) * 0.1).requires_grad_(True)
 xp = xw.clone().requires_grad_(True)
-xg = parallel._AllGatherRows.apply(xp, dg.counts, None, 3, True)
+xg = parallel._gather_rows(xp, dg.counts, None, 3, True)
 pend = parallel.pending_of(xg)
 assert pend is not None and len(pend.slices) == 3
 amax = parallel.all_reduce_max(ops_gemm.amax(xp.detach()), dg)
@@ -53,7 +53,7 @@ ref_q = xw.double() @ w64.detach().double()
 assert float((q.detach().double() - ref_q).abs().max()) <= 2e-6 * float(ref_q.abs().max())
 q.sum().backward()
 assert torch.allclose(xp.grad, w64.detach().sum(1).expand(n, 64), rtol=1e-5, atol=1e-5)
-xg2 = parallel._AllGatherRows.apply(xw, dg.counts, None, 4, True)
+xg2 = parallel._gather_rows(xw, dg.counts, None, 4, True)
 assert torch.equal(parallel.finish(xg2), xw) and parallel.pending_of(xg2) is None
 # the list form of all-gather (what ragged, nnz-balanced ranges use)
 bufs = [torch.empty_like(x)]

@@ -1,6 +1,8 @@
-"""world_size-2 `gloo` tests (CPU) of the row-range sharding: partition covers every edge once,
-the per-layer all-gather (equal and ragged row counts, with autograd), and the global loss
-reduction.  The edge math itself is stood in for by the oracle (tests only)."""
+"""`gloo` tests (CPU) of the row-range sharding at world sizes 2, 4 and 8 (BASELINE's configs[3] / [4] run on 4 / 8 ranks):
+partition covers every edge once, the per-layer all-gather (equal and ragged row counts - at 8 ranks some own a handful of
+rows, slices are ragged and padded - with autograd), the adjoint started early by its producer, the halo exchange, the
+gradient bucket with ranks that produced no gradient, and the global loss reduction.  The edge math itself is stood in for
+by the oracle (tests only)."""
 import os
 import socket
 
@@ -153,6 +155,123 @@ def _worker(rank, world, port, q):
         q.put((rank, traceback.format_exc()))
 
 
+def _worker_many(rank, world, port, q):
+    """The exchange paths at any world size: ragged nnz-balanced ranges (ranks of very different row counts), 4 slices with
+    per-slice padding, the adjoint, the adjoint put on the links early by the consumer's backward, the halo exchange, and
+    all_reduce_grads when only some ranks produced a gradient."""
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from edgedisentangle_ssl_amd import parallel
+        from edgedisentangle_ssl_amd.graph import CSRGraph
+        idx, vals, n = ic.tiny_graph()
+        g = CSRGraph.from_index(idx, n)
+        dg = parallel.DistGraph.shard(g, rank, world)
+        counts = dg.counts
+        assert sum(counts) == n and dg.n == counts[rank] and len(counts) == world
+        if world >= 4:
+            assert len(set(counts)) > 1                     # ragged: the hub row's rank owns few rows
+        nnz = torch.tensor([dg.nnz])
+        dist.all_reduce(nnz)
+        assert int(nnz) == g.nnz
+        lo = dg.row_start
+        tot = world * (world + 1) / 2.0                      # sum over ranks of (rank + 1)
+        x = ic.features(21, n, 16)
+        w = torch.arange(n, dtype=torch.float32).unsqueeze(1)
+        want = (w * tot).expand(n, 16)[lo:lo + dg.n]
+        for slices in ("1", "4", "64"):
+            os.environ["DISGAT_EXCHANGE_SLICES"] = slices
+            xp = x[lo:lo + dg.n].clone().requires_grad_(True)
+            wq = ic.features(5, 16, 24).requires_grad_(True)
+            xg_, g_eff = parallel.exchange(xp, dg, edge_only=False, pipelined=True)
+            assert g_eff is dg
+            if world > 1 and max(counts) > 0 and any(c for r, c in enumerate(counts) if r != rank):
+                assert parallel.pending_of(xg_) is not None
+            qq = parallel.project_gathered(xg_, wq)
+            assert parallel.pending_of(xg_) is None and torch.equal(xg_.detach(), x)
+            assert torch.allclose(qq.detach(), x @ wq.detach(), atol=1e-5)
+            cw = torch.cos(torch.arange(n * 24, dtype=torch.float32).view(n, 24))
+            ((qq * cw * (rank + 1)).sum() + (xg_ * w * (rank + 1)).sum()).backward()
+            want_x = ((cw * tot) @ wq.detach().t() + w * tot)[lo:lo + dg.n]
+            assert torch.allclose(xp.grad, want_x, atol=2e-4 * world)
+            assert torch.allclose(wq.grad, x.t() @ (cw * (rank + 1)), atol=1e-3)
+            xq = x[lo:lo + dg.n].clone().requires_grad_(True)
+            xg2, _ = parallel.exchange(xq, dg, edge_only=False, pipelined=True)
+            assert torch.equal(parallel.finish(xg2).detach(), x) and parallel.pending_of(xg2) is None
+            (xg2 * w * (rank + 1)).sum().backward()
+            assert torch.allclose(xq.grad, want)
+        os.environ.pop("DISGAT_EXCHANGE_SLICES")
+
+        # the adjoint started by its producer: a consumer whose backward finishes grad x_all, puts the reduce-scatter on the
+        # links (parallel.start_adjoint), goes on with other work (here: its weight gradient) and returns; the gather's own
+        # backward then only collects the result - same gradients as the plain path
+        class Consumer(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, x_all, wgt):
+                ctx.save_for_backward(x_all, wgt)
+                ctx.x_all = x_all
+                return x_all @ wgt
+
+            @staticmethod
+            def backward(ctx, go):
+                x_all, wgt = ctx.saved_tensors
+                gx = go @ wgt.t()
+                assert parallel.start_adjoint(ctx.x_all, gx)
+                gw = x_all.t() @ go                       # runs while the reduce-scatter is on the links
+                return gx, gw
+        before = parallel.ADJOINT_EARLY_STARTS
+        xe = x[lo:lo + dg.n].clone().requires_grad_(True)
+        we = ic.features(6, 16, 8).requires_grad_(True)
+        xa, _ = parallel.exchange(xe, dg, edge_only=False, pipelined=True)
+        parallel.finish(xa)
+        co = torch.sin(torch.arange(n * 8, dtype=torch.float32).view(n, 8)) * (rank + 1)
+        (Consumer.apply(xa, we) * co).sum().backward()
+        assert parallel.ADJOINT_EARLY_STARTS == before + 1
+        co_tot = torch.sin(torch.arange(n * 8, dtype=torch.float32).view(n, 8)) * tot
+        assert torch.allclose(xe.grad, (co_tot @ we.detach().t())[lo:lo + dg.n], atol=1e-4 * world)
+        assert torch.allclose(we.grad, x.t() @ co, atol=1e-3)
+        assert not parallel.start_adjoint(x, x)           # not a gathered table: no-op
+        # two consumers of one table: autograd sums their gradients into a new tensor, the early result is for one of them
+        # only and must NOT be taken - the plain path runs (and is correct)
+        xe2 = x[lo:lo + dg.n].clone().requires_grad_(True)
+        xa2, _ = parallel.exchange(xe2, dg, edge_only=False)
+        ((Consumer.apply(xa2, we.detach()) * co).sum() + (xa2 * w * (rank + 1)).sum()).backward()
+        assert torch.allclose(xe2.grad, (co_tot @ we.detach().t() + w * tot)[lo:lo + dg.n], atol=1e-4 * world)
+
+        # halo exchange + its fixed-order adjoint
+        os.environ["DISGAT_EXCHANGE"] = "halo"
+        xh = x[lo:lo + dg.n].clone().requires_grad_(True)
+        x_ref, gc = parallel.exchange(xh, dg, edge_only=True)
+        plan = dg._halo
+        assert torch.equal(x_ref.detach(), x[plan.ref]) and torch.equal(plan.ref[gc.col.long()], dg.col.long())
+        (x_ref * w[plan.ref] * (rank + 1)).sum().backward()
+        refd = torch.zeros(n)
+        refd[plan.ref] = 1.0
+        cnt = refd * (rank + 1)
+        dist.all_reduce(cnt)
+        assert torch.allclose(xh.grad, (torch.arange(n, dtype=torch.float32) * cnt).unsqueeze(1).expand(n, 16)[lo:lo + dg.n])
+        os.environ.pop("DISGAT_EXCHANGE")
+
+        # gradient bucket: a parameter only the even ranks have a gradient for, one nobody has, one everybody has
+        lin = torch.nn.Linear(3, 2)
+        extra = torch.nn.Linear(2, 2)
+        with torch.no_grad():
+            for prm in list(lin.parameters()) + list(extra.parameters()):
+                prm.fill_(0.5)
+        lin.weight.grad = torch.full_like(lin.weight, float(rank + 1))
+        lin.bias.grad = torch.full_like(lin.bias, 2.0) if rank % 2 == 0 else None
+        parallel.all_reduce_grads([lin, extra], dg)
+        assert torch.equal(lin.weight.grad, torch.full_like(lin.weight, tot))
+        assert torch.equal(lin.bias.grad, torch.full_like(lin.bias, 2.0 * ((world + 1) // 2)))
+        assert extra.weight.grad is None and extra.bias.grad is None
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc()))
+
+
 def _run_ranks(target, world, args=(), timeout=240):
     import queue
     ctx = mp.get_context("spawn")
@@ -183,6 +302,14 @@ def _run_ranks(target, world, args=(), timeout=240):
 
 def test_row_sharding_world2():
     _run_ranks(_worker, 2)
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_exchange_paths_at_baseline_world_sizes(world):
+    _run_ranks(_worker_many, world)
 
 
 def test_balanced_ranges_skewed():
