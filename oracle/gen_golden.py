@@ -7,7 +7,7 @@ travels to the GPU box); the product never imports this.  The reference's .py
 files are imported in place with an in-memory `ipdb` stub; nothing
 is copied out of them - fixtures hold inputs-by-seed and expected OUTPUTS only.
 
-Usage:  python oracle/gen_golden.py [--only tiny|prims|traj|traj_real|labels|real]
+Usage:  python oracle/gen_golden.py [--only tiny|prims|traj|traj_real|labels|real|grads_real]
 """
 import argparse
 import os
@@ -512,6 +512,42 @@ def gen_real(skip_existing=False):
                 full["get_em_0"].sum(), full["get_em_1"].sum(), out["loss_sup"], out["loss_dis"], out["loss_dif"]))
 
 
+GRAD_REAL = (("cora", "AT", 3), ("cora", "SAGE", 1), ("chameleon", "AT", 3), ("chameleon", "SAGE", 1))
+GRAD_REAL_HEADS = (0, 3, 7)
+
+
+def gen_grads_real():
+    """First-step parameter gradients on the real graphs: one loss.backward() per reference trainer
+    (pretrainer.py:750-752, 629-631, 834-836) at H = 8, nhid = 64 with the fixtures' own pair lists - before Adam's sign
+    amplification a gradient is well conditioned and can be pinned per element.  Kept: every parameter's sum and absolute
+    sum; the full gradient of heads 0, 3, 7 of both layers and of every trainer-side parameter (fusers, classifiers)."""
+    for name, gnn, att in GRAD_REAL:
+        idx, labels, feat, n = load_real(name)
+        ei = torch.from_numpy(idx)
+        lab = torch.from_numpy(labels)
+        x = torch.from_numpy(feat) if feat is not None else ic.features(51, n, 64, "cora_surrogate")
+        adj = sparse_adj(ei, torch.ones(ei.shape[1]), n)
+        pos, homo, het = ic.edge_sets(ei, lab, n)
+        sup_idx, sup_lab = ic.sample_pairs(61, n, pos, "sup")
+        ho_idx, ho_lab = ic.sample_pairs(62, n, homo, "homo")
+        he_idx, he_lab = ic.sample_pairs(63, n, het, "het")
+        full = {}
+        run_case(x, adj, n, lab, gnn, att, 8, 64, 200 + att, [sup_idx], (sup_lab, [sup_idx]),
+                 ([ho_lab, he_lab], [ho_idx, he_idx]), True, full)
+        out = {k: full[k] for k in ("loss_sup", "loss_dis", "loss_dif")}
+        for k, v in full.items():
+            if not k.startswith("g") or "." not in k or k.split(".")[0] not in ("gsup", "gdis", "gdif"):
+                continue
+            out[k + "#sum"] = np.float64(v.astype(np.float64).sum())
+            out[k + "#abs"] = np.float64(np.abs(v.astype(np.float64)).sum())
+            part = k.split(".")[2] if k.split(".")[1] == "enc" else ""
+            head = int(part.split("_")[1]) if part.startswith("attention") else None
+            if (head is None and not part.startswith("fuser")) or head in GRAD_REAL_HEADS:
+                out[k] = v
+        np.savez_compressed(os.path.join(GOLD, f"{name}_grads_{gnn}_att{att}.npz"), **out)
+        print("grads_real", name, gnn, att, "arrays", len(out), "sup %.8f dis %.8f dif %.6f" % (out["loss_sup"], out["loss_dis"], out["loss_dif"]))
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -533,4 +569,6 @@ if __name__ == "__main__":
             gen_labels()
         if o.only in (None, "real"):
             gen_real(o.skip_existing)
+        if o.only in (None, "grads_real"):
+            gen_grads_real()
         os.chdir(REPO)

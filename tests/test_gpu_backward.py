@@ -230,3 +230,65 @@ def test_gradients_repeat_bit_for_bit(golden_dir, dev, att, monkeypatch):
     assert runs[0].keys() == runs[1].keys() and len(runs[0]) > 10
     for k in runs[0]:
         assert torch.equal(runs[0][k], runs[1][k]), k
+
+
+GRAD_REAL = [("cora", "AT", 3), ("cora", "SAGE", 1), ("chameleon", "AT", 3), ("chameleon", "SAGE", 1)]
+
+
+@pytest.mark.parametrize("name,gnn,att", GRAD_REAL)
+def test_real_graph_first_step_gradients(golden_dir, dev, name, gnn, att):
+    """the parameter gradients of ONE loss.backward() per trainer on Cora / chameleon at H = 8, nhid = 64,
+    recorded from the unmodified reference's train_step (pretrainer.py:750-752, 629-631, 834-836; oracle/gen_golden.py
+    --only grads_real, the fixtures' own pair lists).  Before Adam's sign amplification a gradient is well conditioned:
+    every element of the recorded heads (0, 3, 7 of both layers) and of every trainer-side parameter within
+    2e-4 * max |ref| of its tensor, and every parameter's sum within 2e-4 of its absolute sum."""
+    g = np.load(os.path.join(golden_dir, f"{name}_grads_{gnn}_att{att}.npz"))
+    x, adj, n, ei, sup, ho, he = real_inputs(golden_dir, name, dev)
+    sup, ho, he = ([t.to(dev) for t in lst] for lst in (sup, ho, he))
+    seed = 200 + att
+    a, enc, _ = build(gnn, att, 8, 64, x.shape[1], seed, dev)
+    sup_t, dis_t, dif_t = _trainers(a, enc, seed, dev)
+    data = (x, adj)
+    checked = {"elem": 0, "sum": 0}
+
+    def compare(prefix, module):
+        for k, p in module.named_parameters():
+            key = f"{prefix}.{k}"
+            if key + "#sum" not in g.files:
+                continue
+            got = (p.grad if p.grad is not None else torch.zeros_like(p)).detach().double().cpu().numpy()
+            ref_abs = float(g[key + "#abs"])
+            assert abs(got.sum() - float(g[key + "#sum"])) <= 2e-4 * ref_abs + 1e-12, (key, got.sum(), float(g[key + "#sum"]), ref_abs)
+            checked["sum"] += 1
+            if key in g.files:
+                ref = g[key].astype(np.float64)
+                scale = float(np.abs(ref).max())
+                err = float(np.abs(got - ref).max())
+                assert err <= 2e-4 * scale + 1e-12, f"{key}: max|d| = {err:.3e} > 2e-4 * {scale:.3e}"
+                checked["elem"] += 1
+
+    def zero(tr):
+        for m in tr.models:
+            for p in m.parameters():
+                p.grad = None
+
+    zero(sup_t)
+    loss = sup_t.loss(data, sup[1], [sup[0]])
+    assert abs(loss.item() - float(g["loss_sup"])) <= 2e-5 * max(1.0, abs(float(g["loss_sup"])))
+    loss.backward()
+    compare("gsup.enc", enc)
+    compare("gsup.fuse1", sup_t.fuse1)
+    zero(dis_t)
+    loss = dis_t.loss(data, [ho[1], he[1]], [ho[0], he[0]])
+    assert abs(loss.item() - float(g["loss_dis"])) <= 2e-5 * max(1.0, abs(float(g["loss_dis"])))
+    loss.backward()
+    compare("gdis.enc", enc)
+    zero(dif_t)
+    loss = dif_t.loss(data)
+    assert abs(loss.item() - float(g["loss_dif"])) <= 2e-5 * max(1.0, abs(float(g["loss_dif"])))
+    loss.backward()
+    compare("gdif.enc", enc)
+    compare("gdif.cls1", dif_t.classifier1)
+    compare("gdif.fuse1", dif_t.fuse1)
+    compare("gdif.fuse2", dif_t.fuse2)
+    assert checked["elem"] >= 3 * 6 * 3 and checked["sum"] >= 3 * 16 * 3, checked
