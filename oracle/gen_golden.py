@@ -7,7 +7,7 @@ travels to the GPU box); the product never imports this.  The reference's .py
 files are imported in place with an in-memory `ipdb` stub; nothing
 is copied out of them - fixtures hold inputs-by-seed and expected OUTPUTS only.
 
-Usage:  python oracle/gen_golden.py [--only tiny|prims|traj|traj_real|labels|real|grads_real]
+Usage:  python oracle/gen_golden.py [--only tiny|prims|traj|traj_real|labels|real|grads_real|tiny256]
 """
 import argparse
 import os
@@ -548,6 +548,46 @@ def gen_grads_real():
         print("grads_real", name, gnn, att, "arrays", len(out), "sup %.8f dis %.8f dif %.6f" % (out["loss_sup"], out["loss_dis"], out["loss_dif"]))
 
 
+TINY256 = dict(n=2048, e=40960, f=256, nhid=256, heads=4)
+
+
+def gen_tiny256():
+    """A fixture at a width the plane-operand GEMM chain tiles (nhid 64 on the bundled graphs never engages
+    csrc/gemm_planes.hip, so the chain bench.py times had only met the float64 oracle): SURVEY 8(d)'s power-law generator
+    at N = 2 048 / E = 40 960, F_in = nhid = 256, H = 4, att 3, AT and SAGE - the reference's five entry points and three
+    losses; 256-row slices, column sums and strided score samples are kept."""
+    c = TINY256
+    n = c["n"]
+    idx = ic.powerlaw_index(1234, n, c["e"])
+    ci = ic.coalesced_index_set(idx, n)
+    adj = sparse_adj(idx, torch.ones(idx.shape[1]), n)
+    x = ic.features(71, n, c["f"])
+    labels = torch.from_numpy(np.random.Generator(np.random.PCG64(7)).integers(0, 4, n))
+    pos, homo, het = ic.edge_sets(ci, labels, n)
+    sup_idx, sup_lab = ic.sample_pairs(81, n, pos, "sup")
+    ho_idx, ho_lab = ic.sample_pairs(82, n, homo, "homo")
+    he_idx, he_lab = ic.sample_pairs(83, n, het, "het")
+    for gnn in ("AT", "SAGE"):
+        full = {}
+        run_case(x, adj, n, labels, gnn, 3, c["heads"], c["nhid"], 400, [sup_idx], (sup_lab, [sup_idx]),
+                 ([ho_lab, he_lab], [ho_idx, he_idx]), False, full)
+        out = {k: full[k] for k in ("loss_sup", "loss_dis", "loss_dif")}
+        for k in ("forward", "get_em_0", "get_em_1"):
+            out[k + "_head"] = full[k][:256]
+            out[k + "_colsum"] = full[k].astype(np.float64).sum(0)
+            out[k + "_abssum"] = np.float64(np.abs(full[k].astype(np.float64)).sum())
+        for l in range(2):
+            out[f"adjs_{l}_sub"] = full[f"adjs_{l}"][:, :: max(1, ci.shape[1] // 2048)]
+            out[f"adjs_{l}_sum"] = full[f"adjs_{l}"].astype(np.float64).sum(1)
+            out[f"aux_{l}_0_sub"] = full[f"aux_{l}_0"][:, :: max(1, sup_idx.shape[1] // 2048)]
+            out[f"aux_{l}_0_sum"] = full[f"aux_{l}_0"].astype(np.float64).sum(1)
+            out[f"edge_em_{l}_head"] = full[f"edge_em_{l}"][:, :64]
+            out[f"edge_em_{l}_sum"] = full[f"edge_em_{l}"].astype(np.float64).sum((1, 2))
+        np.savez_compressed(os.path.join(GOLD, f"tiny256_{gnn}_att3.npz"), **out)
+        print("tiny256", gnn, "nnz", ci.shape[1], "M", sup_idx.shape[1], "sum_em0 %.6e sup %.8f dis %.8f dif %.6f" % (
+            full["get_em_0"].sum(), out["loss_sup"], out["loss_dis"], out["loss_dif"]))
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -571,4 +611,6 @@ if __name__ == "__main__":
             gen_real(o.skip_existing)
         if o.only in (None, "grads_real"):
             gen_grads_real()
+        if o.only in (None, "tiny256"):
+            gen_tiny256()
         os.chdir(REPO)

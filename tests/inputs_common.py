@@ -80,6 +80,21 @@ def tiny_graph(seed=11, n=64, n_und=170):
     return idx, torch.from_numpy(vals), n
 
 
+def powerlaw_index(seed, n, e_target):
+    """SURVEY 8(d)'s synthetic power-law graph (the generator bench.py times, edgedisentangle_ssl_amd/synth.py) as a raw
+    index list [2, nnz_raw] with duplicates: m = (E - N) // 2 undirected edges r -> c, r drawn with weights (i+1)^-0.8
+    through a random permutation, c uniform; both directions + self loops."""
+    g = np.random.Generator(np.random.PCG64(int(seed)))
+    m = (e_target - n) // 2
+    w = (np.arange(n, dtype=np.float64) + 1.0) ** -0.8
+    w /= w.sum()
+    perm = g.permutation(n)
+    r = perm[g.choice(n, m, p=w)].astype(np.int64)
+    c = g.integers(0, n, m).astype(np.int64)
+    loop = np.arange(n, dtype=np.int64)
+    return torch.from_numpy(np.stack([np.concatenate([r, c, loop]), np.concatenate([c, r, loop])]))
+
+
 def features(seed, n, f, kind="randn"):
     g = _rng(seed, "features_" + kind)
     if kind == "randn":

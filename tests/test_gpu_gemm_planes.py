@@ -138,3 +138,70 @@ def test_foreign_fuser_still_receives_fp32_heads():
     with torch.no_grad():
         out = enc.get_em(synth.features(n, f, dev), synth.powerlaw_graph(n, 40_000, dev), [foreign, foreign])
     assert all(ln == H for _t, ln in seen) and torch.isfinite(out[1]).all()
+
+
+@pytest.mark.parametrize("gnn", ["AT", "SAGE"])
+def test_plane_chain_meets_a_reference_output(gnn, golden_dir):
+    """the plane-operand chain (edge pass -> Z planes -> projection -> head planes -> fuser / DifHead
+    classifier) never engages at the bundled graphs' nhid = 64, so it had only met the float64 oracle.  tiny256_*.npz holds
+    the UNMODIFIED reference's outputs at a width the chain tiles (SURVEY 8(d)'s generator, N = 2 048, F_in = nhid = 256,
+    H = 4, att 3; oracle/gen_golden.py --only tiny256): the five entry points and the three losses at north_star's 1e-4,
+    with the launcher counted to prove the chain ran."""
+    import os
+    import numpy as np
+    import inputs_common as ic
+    from edgedisentangle_ssl_amd import _lib
+    from test_gpu_parity import TOL, build, close
+    from test_gpu_backward import _trainers
+    dev = torch.device("cuda:0")
+    g = np.load(os.path.join(golden_dir, f"tiny256_{gnn}_att3.npz"))
+    n, e, f, heads = 2048, 40960, 256, 4
+    idx = ic.powerlaw_index(1234, n, e)
+    ci = ic.coalesced_index_set(idx, n)
+    adj = torch.sparse_coo_tensor(idx, torch.ones(idx.shape[1]), (n, n)).to(dev)
+    x = ic.features(71, n, f).to(dev)
+    labels = torch.from_numpy(np.random.Generator(np.random.PCG64(7)).integers(0, 4, n))
+    pos, homo, het = ic.edge_sets(ci, labels, n)
+    sup = [t.to(dev) for t in ic.sample_pairs(81, n, pos, "sup")]
+    ho = [t.to(dev) for t in ic.sample_pairs(82, n, homo, "homo")]
+    he = [t.to(dev) for t in ic.sample_pairs(83, n, het, "het")]
+    a, enc, fus = build(gnn, 3, heads, f, f, 400, dev)
+    calls = {}
+    real_call = _lib.call
+
+    def counting(name, *args):
+        calls[name] = calls.get(name, 0) + 1
+        return real_call(name, *args)
+    _lib.call = counting
+    try:
+        with torch.no_grad():
+            fwd = enc(x, adj, fus)
+            em = enc.get_em(x, adj, fus)
+            n_planes = calls.get("disgat_gemm_planes", 0)
+            adjs = enc.get_adjs(x, adj, fus)
+            auxs = enc.predict_adjs_sparse(x, adj, fus, [sup[0]])
+            eem = enc.get_edge_em(x, adj, fus)
+            sup_t, dis_t, dif_t = _trainers(a, enc, 400, dev)
+            l_sup = sup_t.loss((x, adj), sup[1], [sup[0]])
+            l_dis = dis_t.loss((x, adj), [ho[1], he[1]], [ho[0], he[0]])
+            before = calls.get("disgat_gemm_planes", 0)
+            l_dif = dif_t.loss((x, adj))
+            n_dif = calls.get("disgat_gemm_planes", 0) - before
+    finally:
+        _lib.call = real_call
+    assert n_planes >= 2 * 4 and n_dif >= 6, calls           # forward + get_em: projection and fuser of both layers; DifHead: + classifier
+    for key, t in (("forward", fwd), ("get_em_0", em[0]), ("get_em_1", em[1])):
+        close(t[:256], g[key + "_head"], what=f"{key} head rows")
+        scale = max(1.0, float(g[key + "_abssum"]) / t.numel() * 50)
+        assert np.abs(t.double().sum(0).cpu().numpy() - g[key + "_colsum"]).max() <= TOL * scale * n, f"{key} column sums"
+    stride, astride = max(1, ci.shape[1] // 2048), max(1, sup[0].shape[1] // 2048)
+    for l in range(2):
+        close(torch.stack([t[:, 0] for t in adjs[l]])[:, ::stride], g[f"adjs_{l}_sub"], what=f"adjs {l}")
+        close(torch.stack([h[0][:, 0] for h in auxs[l]])[:, ::astride], g[f"aux_{l}_0_sub"], what=f"aux {l}")
+        ee = torch.stack(list(eem[l]))
+        close(ee[:, :64], g[f"edge_em_{l}_head"], what=f"edge_em {l} head rows")
+        ref = g[f"edge_em_{l}_sum"]
+        assert np.abs(ee.double().sum((1, 2)).cpu().numpy() - ref).max() <= TOL * max(1.0, np.abs(ref).max()) * 10
+    for key, got in (("loss_sup", l_sup), ("loss_dis", l_dis), ("loss_dif", l_dif)):
+        want = float(g[key])
+        assert abs(got.item() - want) <= 1e-5 * max(1.0, abs(want)), (key, got.item(), want)
