@@ -46,4 +46,27 @@ __device__ __forceinline__ float act_ct(float v, float slope) {
   return v;
 }
 
+
+// Arguments of the fp32-operand f16x3 launchers (disgat_gemm_f16x3: gemm_split.hip, gemm_rs.hip)
+struct GemmHArgs {
+  const float* A;
+  int64_t lda, a_bs;
+  const uint16_t* Bt;    // [batch][2][N][K] fp16: hi, lo of (B^T * s_B), k contiguous
+  const float* a_amax;   // device scalar: max |A| over the whole operand (disgat_amax)
+  const float* b_scale;  // device scalar: s_B used for Bt
+  const float* bias;
+  const float* init;
+  int64_t ldi, i_bs;
+  float* C;
+  int64_t ldc, c_bs;
+  int M, N, K, batch;
+  int act;
+  float slope;
+  int mt, nt;
+};
+
+// gemm_rs.hip: the register-stationary kernel for K in {64, 128, 256} (host side)
+bool gemm_rs_takes(int N, int K);
+int launch_gemm_f16x3_rs(const GemmHArgs& G, hipStream_t st);
+
 }  // namespace disgat

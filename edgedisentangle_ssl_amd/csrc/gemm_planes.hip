@@ -11,7 +11,7 @@
 // (projection -> FuseLayer, layers.py:905) - used to split fp32 -> (hi, lo) on the fly: 2.6-3.8 VALU instructions per
 // MFMA, one block per CU, load -> split -> barrier -> MFMA -> store in series (20 us per 128-row tile of which 5 us
 // MFMA).  Here the producers store the planes (same bytes as fp32) and this kernel does no operand arithmetic at all:
-//   * persistent 512-thread blocks, one per CU, each walking a contiguous range of (row tile, column step, head) units
+//   * persistent 512-thread blocks, one per CU, each walking a contiguous range of (head, row tile, column step) units
 //     with the k-loop running on across units - loads of the next unit are in flight during a unit's epilogue;
 //   * both operands reach LDS by global_load_lds_dwordx4 (no VGPR staging, no ds_write), 1 KB = 16 rows x 64 B per
 //     wave instruction, XOR-swizzled through the per-lane SOURCE address (the LDS image of a DMA is lane-linear);
@@ -50,7 +50,7 @@ struct GemmPArgs {
   int M, N, K, batch;
   float slope;
   int nsteps, units;       // column steps of 256; units = row tiles x nsteps x batch
-  int dbg;                 // ablation switches (DISGAT_PL_DEBUG): 1 no stores, 2 no MFMA, 4 A rows from a cache-resident range
+  int dbg;                 // switches (DISGAT_PL_DEBUG): 64 = round 3's unit map; with DISGAT_PL_DIAG: 1 no stores, 2 no MFMA, 4 A rows from a cache-resident range
 };
 
 constexpr int PL_BM = 128, PL_BN = 256;
@@ -101,9 +101,17 @@ __global__ __launch_bounds__(512, 1) void gemm_planes_kernel(const GemmPArgs G) 
   const int wrow = ld_wave ? 16 * MC : 0;                   // first tile row of this wave's 64-column strip
   const int KT = G.K >> 5;
 
-  const int ub = (int)((int64_t)G.units * blockIdx.x / gridDim.x);
-  const int ue = (int)((int64_t)G.units * (blockIdx.x + 1) / gridDim.x);
+  // XCD-aware unit map.  Units are ordered HEAD-major and the blocks of one XCD (blockIdx.x % 8 under the round-robin
+  // dispatch) take a contiguous eighth of them: with 8 heads every XCD works on ONE head's weight planes at a time (256 KB
+  // in its 4 MB L2) instead of cycling through all 2 MB of them per row tile beside the streamed A tiles, which evicted
+  // the weights about once in four (projection: 12.3 GB read for 8.2 GB of operand, profiles/r03/gemm_f16x3_pmc.md).  The
+  // 8 XCDs still walk the same rows at the same time, so a row's [H][F_in] segments are read together.
+  const bool xmap = gridDim.x % 8 == 0 && !(G.dbg & 64);    // DISGAT_PL_DEBUG=64: round 3's map (same-box A/B)
+  const int vb = xmap ? (int)(blockIdx.x % 8) * (int)(gridDim.x / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+  const int ub = (int)((int64_t)G.units * vb / gridDim.x);
+  const int ue = (int)((int64_t)G.units * (vb + 1) / gridDim.x);
   if (ub >= ue) return;
+  const int per_head = G.units / G.batch;
 
   const float sA = f16_scale(*G.a_bound);
   const float sAB = sA * *G.b_scale;
@@ -113,8 +121,14 @@ __global__ __launch_bounds__(512, 1) void gemm_planes_kernel(const GemmPArgs G) 
   if constexpr (PL) sC = f16_scale(*G.c_bound);
 
   auto decode = [&](int u, int& m0, int& n0, int& bz) __attribute__((always_inline)) {
-    bz = u % G.batch;
-    const int r = u / G.batch;
+    int r;
+    if (xmap) {
+      bz = u / per_head;
+      r = u - bz * per_head;
+    } else {
+      bz = u % G.batch;
+      r = u / G.batch;
+    }
     n0 = (r % G.nsteps) * PL_BN;
     m0 = (r / G.nsteps) * PL_BM;
   };

@@ -267,22 +267,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs G) {
 // subnormal range for all but the largest elements).  C = (acc_hh + 2^-11 acc_x) / (s_A s_B).
 // Measured error vs fp64: tests/test_gpu_gemm.py (yardstick hipBLASLt fp32).
 
-struct GemmHArgs {
-  const float* A;
-  int64_t lda, a_bs;
-  const uint16_t* Bt;    // [batch][2][N][K] fp16: hi, lo of (B^T * s_B), k contiguous
-  const float* a_amax;   // device scalar: max |A| over the whole operand (disgat_amax)
-  const float* b_scale;  // device scalar: s_B used for Bt
-  const float* bias;
-  const float* init;
-  int64_t ldi, i_bs;
-  float* C;
-  int64_t ldc, c_bs;
-  int M, N, K, batch;
-  int act;
-  float slope;
-  int mt, nt;
-};
+// struct GemmHArgs: gemm_common.h (shared with gemm_rs.hip)
 
 __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(const GemmHArgs G) {
   __shared__ __attribute__((aligned(16))) uint16_t lds[17408];      // 4 planes (32 KB) | epilogue stage (33.8 KB)
@@ -1050,6 +1035,10 @@ extern "C" int disgat_gemm_f16x3(const float* A, int64_t lda, int64_t a_batch_st
   const int64_t blocks = (int64_t)((G.mt + 7) / 8) * 8 * G.nt;
   DISGAT_REQUIRE(blocks < ((int64_t)1 << 31) && batch < 65536, "gemm_f16x3: grid too large");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  // K = 64 / 128 / 256: A register-stationary, weights through an LDS ring (gemm_rs.hip); DISGAT_GEMM_AS=1 keeps the
+  // A-in-LDS kernel below for those shapes too (same-box A/B)
+  static const bool force_as = getenv("DISGAT_GEMM_AS") && atoi(getenv("DISGAT_GEMM_AS")) != 0;
+  if (!force_as && gemm_rs_takes(N, K)) return launch_gemm_f16x3_rs(G, st);
   if (K <= 256) {                       // A-stationary: the whole 128 x K A tile lives in LDS (dynamic, > 64 KB)
     const int lds_bytes = 2 * AS_BM * (K + AS_PAD) * (int)sizeof(uint16_t);
     static int lds_set = 0;

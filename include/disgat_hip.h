@@ -293,6 +293,8 @@ int disgat_planes_to_f32(const uint16_t* P_hi, const uint16_t* P_lo, int64_t ldp
  * every block ([2][8]: wait, barrier, fragment reads + DMA issue, MFMA, epilogue, unit set-up); copies them out
  * (out16 may be NULL) and optionally zeroes them.  Synchronises the device. */
 int disgat_debug_stamps(unsigned long long* out16, int reset);
+/* The same for disgat_gemm_f16x3's register-stationary kernel (a -DRS_DIAG=1 build, DISGAT_RS_DEBUG & 32; csrc/gemm_rs.hip). */
+int disgat_debug_stamps_rs(unsigned long long* out16, int reset);
 
 /* Backward of the epilogue activation from the saved output (n contiguous floats, n % 4 == 0):
  * gin = g * (out > 0 ? 1 : (act == 1 ? out + 1 : slope)); act 1 = ELU, 2 = leaky ReLU.  gin may alias g.
