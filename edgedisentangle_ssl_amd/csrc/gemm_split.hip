@@ -1026,7 +1026,8 @@ extern "C" int disgat_gemm_f16x3(const float* A, int64_t lda, int64_t a_batch_st
   using namespace disgat;
   if (M == 0 || batch == 0) return 0;
   DISGAT_REQUIRE(A && Bt_planes && C && a_amax && b_scale && M > 0 && batch > 0, "gemm_f16x3: null pointer / bad sizes");
-  DISGAT_REQUIRE(N > 0 && N % GBN == 0 && K > 0 && K % GBK == 0, "gemm_f16x3: N=%d must be a multiple of %d and K=%d of %d", N, GBN, K, GBK);
+  DISGAT_REQUIRE(N > 0 && K > 0 && K % GBK == 0 && (N % GBN == 0 || gemm_rs_takes(N, K)),
+                 "gemm_f16x3: N=%d must be a multiple of %d (of 32 for K = 64 / 128 / 256) and K=%d of %d", N, GBN, K, GBK);
   DISGAT_REQUIRE(lda % 4 == 0 && a_batch_stride % 4 == 0 && aligned16(A) && aligned16(Bt_planes),
                  "gemm_f16x3: A rows must be 16-byte aligned (lda, batch stride multiples of 4)");
   DISGAT_REQUIRE(act >= 0 && act <= 2, "gemm_f16x3: act must be 0 (none), 1 (elu) or 2 (leaky relu)");
@@ -1038,7 +1039,7 @@ extern "C" int disgat_gemm_f16x3(const float* A, int64_t lda, int64_t a_batch_st
   // K = 64 / 128 / 256: A register-stationary, weights through an LDS ring (gemm_rs.hip); DISGAT_GEMM_AS=1 keeps the
   // A-in-LDS kernel below for those shapes too (same-box A/B)
   static const bool force_as = getenv("DISGAT_GEMM_AS") && atoi(getenv("DISGAT_GEMM_AS")) != 0;
-  if (!force_as && gemm_rs_takes(N, K)) return launch_gemm_f16x3_rs(G, st);
+  if ((!force_as || N % GBN != 0) && gemm_rs_takes(N, K)) return launch_gemm_f16x3_rs(G, st);
   if (K <= 256) {                       // A-stationary: the whole 128 x K A tile lives in LDS (dynamic, > 64 KB)
     const int lds_bytes = 2 * AS_BM * (K + AS_PAD) * (int)sizeof(uint16_t);
     static int lds_set = 0;

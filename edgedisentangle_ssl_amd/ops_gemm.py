@@ -74,8 +74,14 @@ def _apply_act(t, act, slope):
     return t
 
 
+def _tiles(k, n):
+    """Output / reduction widths the f16x3 launcher takes: N % 128 (K % 32), or N % 32 for K = 64 / 128 / 256 (the
+    register-stationary kernel, csrc/gemm_rs.hip - what lets the nhid = 64 layers of the bundled graphs run on it)."""
+    return k % 32 == 0 and (n % 128 == 0 or (mode() == "f16x3" and k in (64, 128, 256) and n % 32 == 0 and n >= 32))
+
+
 def _kernel_ok(a, k, n):
-    return (mode() != "blas" and a.is_cuda and a.dtype == torch.float32 and n % 128 == 0 and k % 32 == 0
+    return (mode() != "blas" and a.is_cuda and a.dtype == torch.float32 and _tiles(k, n)
             and a.stride(-1) == 1 and a.stride(-2) % 4 == 0 and a.data_ptr() % 16 == 0
             and (a.dim() == 2 or a.stride(0) % 4 == 0))
 
@@ -83,7 +89,7 @@ def _kernel_ok(a, k, n):
 def presplit(w):
     """Split planes of a weight for reuse across calls (inference: the weights do not change between forwards);
     None when the active scheme has nothing to precompute for it."""
-    if mode() != "f16x3" or not w.is_cuda or w.shape[-1] % 128 or w.shape[-2] % 32:
+    if mode() != "f16x3" or not w.is_cuda or not _tiles(w.shape[-2], w.shape[-1]):
         return None
     return split_weight_f16(w)
 
@@ -278,6 +284,30 @@ def _weight_grad(a, g, a_amax, g_amax):
     return out if batched else out[0]
 
 
+def _wgrad_blas(a, g):
+    """a^T @ g (2-D, or head-batched [H, M, K] / [H, M, N] views) for the shapes outside the split-K kernel's tiling - the
+    nhid = 64 layers of the bundled graphs.  The reduction runs over the M node rows while the result is a few 16 x 16 tiles:
+    left as ONE GEMM, hipBLASLt gives it a handful of workgroups (77-430 us per call at M = 19 793, a quarter of cora_full's
+    captured epoch).  Cut into row ranges it is a batched GEMM with enough tiles to fill the chip plus a fixed-order sum."""
+    m, k, n = a.shape[-2], a.shape[-1], g.shape[-1]
+    batched = a.dim() == 3
+    hb = a.shape[0] if batched else 1
+    s = min(64, m // 256, max(1, 512 // max(1, hb * -(-k // 64) * -(-n // 64))))
+    if s < 2 or not a.is_cuda:
+        return torch.bmm(a.transpose(1, 2), g) if batched else a.t() @ g
+    rows = m // s
+    head = rows * s
+    if batched:       # [H, M, K] views of [M, H, K] buffers: rows of a range are strided, the batch is (head, range)
+        part = torch.matmul(a[:, :head].reshape(hb, s, rows, k).transpose(2, 3), g[:, :head].reshape(hb, s, rows, n)).sum(1)
+        if head < m:
+            part = part + torch.bmm(a[:, head:].transpose(1, 2), g[:, head:])
+        return part
+    part = torch.bmm(a[:head].reshape(s, rows, k).transpose(1, 2), g[:head].reshape(s, rows, n)).sum(0)
+    if head < m:
+        part = part + a[head:].t() @ g[head:]
+    return part
+
+
 def linear_backward(a, w, g, a_amax=None, need_a=True, need_w=True, g_amax=None, ga_init=None):
     """(grad a, grad w) of a @ w (2-D, no bias / activation) on the f16x3 kernels where their tiling allows.
     g_amax: max |g| (or an upper bound) as a device scalar when the producer of g measured it already;
@@ -292,7 +322,7 @@ def linear_backward(a, w, g, a_amax=None, need_a=True, need_w=True, g_amax=None,
         if g_am is not None and _tn_ok(a, g, a.shape[1], g.shape[1]):
             gw = _weight_grad(a, g, a_amax if a_amax is not None else amax(a), g_am)
         else:
-            gw = a.t() @ g
+            gw = _wgrad_blas(a, g)
     return ga, gw
 
 
@@ -330,7 +360,7 @@ class _Linear(torch.autograd.Function):
                 if g_am is not None and _tn_ok(a, g3, k, g3.shape[2]):
                     gw = _weight_grad(a, g3, ctx.a_amax if ctx.a_amax is not None else amax(a), g_am)
                 else:
-                    gw = torch.bmm(a.transpose(1, 2), g3)
+                    gw = _wgrad_blas(a, g3)
         else:
             if ctx.needs_input_grad[0]:
                 ga = _forward(g, w.t(), None, None, ACT_NONE, 0.0, g_am)
@@ -338,7 +368,7 @@ class _Linear(torch.autograd.Function):
                 if g_am is not None and _tn_ok(a, g, a.shape[1], g.shape[1]):
                     gw = _weight_grad(a, g, ctx.a_amax if ctx.a_amax is not None else amax(a), g_am)
                 else:
-                    gw = a.t() @ g
+                    gw = _wgrad_blas(a, g)
         if has_bias and ctx.needs_input_grad[2]:
             gb = g.sum(0)
         if has_init and ctx.needs_input_grad[3]:

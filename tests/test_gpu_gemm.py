@@ -17,7 +17,8 @@ def scheme(request, monkeypatch):
 
 
 @pytest.mark.parametrize("m,k,n", [(1000, 256, 256), (4096, 64, 512), (777, 2048, 256), (130, 32, 128),
-                                   (70001, 256, 256), (33000, 96, 2048)])
+                                   (70001, 256, 256), (33000, 96, 2048), (19793, 64, 64), (2277, 128, 96), (300, 256, 32),
+                                   (255, 64, 512), (257, 256, 2048)])
 def test_plain_accuracy_matches_fp32_gemm(m, k, n, scheme):
     from edgedisentangle_ssl_amd import ops_gemm
     g = torch.Generator(device="cuda").manual_seed(1)
@@ -230,3 +231,32 @@ def test_skinny_linear_matches_fp64(m, k, n, bias):
     if bias:
         assert torch.allclose(lin.bias.grad, w.sum(0), rtol=1e-5, atol=1e-4)
     assert not ops_gemm.skinny_ok(x[:, :128], lin) and not ops_gemm.skinny_ok(x.cpu(), lin)
+
+
+@pytest.mark.parametrize("m,hb,k,n,act", [(2708, 8, 64, 64, 1), (19793, 8, 64, 64, 1), (1000, 4, 128, 32, 2), (513, 2, 256, 96, 0)])
+def test_narrow_outputs_run_on_the_library_kernel(m, hb, k, n, act, monkeypatch):
+    """N % 32 (not 128) for K = 64 / 128 / 256: the register-stationary kernel (csrc/gemm_rs.hip) takes the nhid = 64 layers
+    of the bundled graphs (per-head projection [64 -> 64] x 8 heads, batched, with bias / additive input / activation) that
+    used to fall to hipBLASLt; against float64, forward and both gradients, and the launcher counted."""
+    from edgedisentangle_ssl_amd import _lib, ops_gemm
+    g = torch.Generator(device="cuda").manual_seed(m + n)
+    z = torch.randn(m, hb, k, device="cuda", generator=g)
+    a = z.permute(1, 0, 2).requires_grad_(True)
+    w = (torch.randn(hb, k, n, device="cuda", generator=g) * 0.1).requires_grad_(True)
+    b = torch.randn(hb * n, device="cuda", generator=g)
+    ini = torch.randn(m, hb * n, device="cuda", generator=g)
+    calls = []
+    real = _lib.call
+    monkeypatch.setattr(_lib, "call", lambda name, *args: (calls.append(name), real(name, *args))[1])
+    out = ops_gemm.linear(a, w, b, ini, act, 0.01)
+    assert calls.count("disgat_gemm_f16x3") == 1
+    pre = (torch.bmm(a.detach().double(), w.detach().double()).permute(1, 0, 2).reshape(m, hb * n) + b.double() + ini.double())
+    ref = {0: lambda t: t, 1: torch.nn.functional.elu, 2: lambda t: torch.nn.functional.leaky_relu(t, 0.01)}[act](pre)
+    assert _err(out.detach(), ref) < 1e-6
+    go = torch.randn(m, hb * n, device="cuda", generator=g)
+    out.backward(go)
+    ad = a.detach().double().requires_grad_(True)
+    wd = w.detach().double().requires_grad_(True)
+    pre = torch.bmm(ad, wd).permute(1, 0, 2).reshape(m, hb * n) + b.double() + ini.double()
+    {0: lambda t: t, 1: torch.nn.functional.elu, 2: lambda t: torch.nn.functional.leaky_relu(t, 0.01)}[act](pre).backward(go.double())
+    assert _err(a.grad, ad.grad) < 2e-6 and _err(w.grad, wd.grad) < 2e-5

@@ -4,7 +4,7 @@ set -u
 ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 NAME=${1:-cora_full}; EP=${2:-60}; OUT="$ROOT/gpurun_out/${3:-r04/epoch_kt_$NAME}"
 mkdir -p "$OUT"
-cd /tmp && export TMPDIR=/tmp
+cd /tmp && export TMPDIR=/tmp PYTHONPATH="$ROOT${PYTHONPATH:+:$PYTHONPATH}"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -- python3 -m edgedisentangle_ssl_amd.main --model=DISGAT --sparse --dataset $NAME \
   --fixture $ROOT/tests/golden/data_$NAME.npz --gnn_type AT --att 3 --nhead 8 --nhid 64 --steps 5 --downstream CLS --down_weight 1.0 --finetune \
   --pretrain SupEdge DisEdge DifHead --pre_weight 1 1 1 --pre_edge 1 1 1 --dropout 0.1 --seed 4 --quiet --epochs $EP --capture on > "$OUT/run.log" 2>&1
