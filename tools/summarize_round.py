@@ -36,9 +36,14 @@ def counters(path):
     out = {}
     for f in newest(os.path.join(path, "*", "*_counter_collection.csv")):
         for r in csv.DictReader(open(f)):
-            k = r["Kernel_Name"].split("(")[0]
+            k = kname_of(r["Kernel_Name"])
             out.setdefault(k, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
     return out
+
+
+def kname_of(full):
+    """Kernel name without its argument list (kernels in anonymous namespaces carry a parenthesis inside the name)."""
+    return full.replace("(anonymous namespace)::", "").split("(")[0]
 
 
 def main(src, dst):
@@ -84,7 +89,8 @@ def main(src, dst):
           "for the duration.  SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles; SQ_VALU_MFMA_BUSY_CYCLES "
           "counts cycles (MI355X_MICROARCH.md).\n")
         for shape, what, flop, kname in (
-                ("pq", "P / Q operands x[1e6,256] x [256,2048], fp32 operand: gemm_f16x3_as_kernel<0> (A-stationary)", 2.0e6 * 256 * 2048, "gemm_f16x3"),
+                ("pq", "P / Q operands x[1e6,256] x [256,2048], fp32 operand: gemm_f16x3_rs_kernel<0,8> (A register-stationary, weights through an LDS-DMA ring; csrc/gemm_rs.hip)", 2.0e6 * 256 * 2048, "gemm_f16x3"),
+                ("pq_as", "the same product on round 3's kernel, gemm_f16x3_as_kernel<0> (A tile in LDS; DISGAT_GEMM_AS=1)", 2.0e6 * 256 * 2048, "gemm_f16x3"),
                 ("proj", "per-head projection, Z planes [1e6,8,256] x [8,256,256] -> ELU -> head planes: gemm_planes_kernel<1,false,true>", 2.0e6 * 8 * 256 * 256, "gemm_planes"),
                 ("fuser", "FuseLayer, head planes [1e6,2048] x [2048,256] + bias, leaky ReLU -> fp32: gemm_planes_kernel<2,true,false>", 2.0e6 * 2048 * 256, "gemm_planes")):
             P(f"\n## {what}\n")
@@ -118,11 +124,30 @@ def main(src, dst):
                 w = vals["SQ_WAVE_CYCLES"]
                 P(f"\nWave time: {vals['SQ_ACTIVE_INST_ANY'] / w * 100:.0f} % issuing, {vals['SQ_WAIT_INST_ANY'] / w * 100:.0f} % "
                   f"issue-stalled, {vals['SQ_WAIT_ANY'] / w * 100:.0f} % parked at s_waitcnt / barrier")
+    if os.path.isdir(os.path.join(src, "sampler_kt")):
+        with open(os.path.join(dst, "sampler_pmc.md"), "w") as out:
+            P = lambda *a: print(*a, file=out)      # noqa: E731
+            P("# SSL pair sampler (csrc/pair_sample.hip) at C4: one SupEdge list of 66.5M pairs over 1M x 1M entries (tools/sampler_time.py)\n")
+            P("Kernel-trace pass for the durations, separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes for the traffic "
+              "(2 x FETCH + WRITE, KiB -> bytes).  Algorithmic bytes of a list: 20 B written per pair (two int64 planes + a float "
+              "label) = 1.33 GB, 80 MB of positive columns + 32 MB of work items read per pass.\n")
+            P("| kernel | calls | avg ms | HBM GB / launch |\n|---|---|---|---|")
+            fe, wr = counters(os.path.join(src, "sampler_fetch")), counters(os.path.join(src, "sampler_write"))
+            for r in one(os.path.join(src, "sampler_kt")):
+                if "pair_sample" not in r["Name"]:
+                    continue
+                k = kname_of(r["Name"])
+                f = fe.get(k, {}).get("FETCH_SIZE", [0])
+                w = wr.get(k, {}).get("WRITE_SIZE", [0])
+                P(f"| `{k[:70]}` | {r['Calls']} | {float(r['AverageNs']) / 1e6:.3f} | {(2 * sum(f) / len(f) + sum(w) / len(w)) * 1024 / 1e9:.2f} |")
+            for line in open(os.path.join(src, "sampler_kt.log"), errors="ignore"):
+                if "sample" in line and "ms" in line:
+                    P("    " + line.rstrip())
     with open(os.path.join(dst, "att2_pmc.md"), "w") as out:
         P = lambda *a: print(*a, file=out)      # noqa: E731
         P("# att 2 (the reference's default --att): edge pass and aux scorer, PMC counters (tools/kbench.py --att 2 --what edge aux)\n")
         P("C4 graph (1M nodes / 20M edges, F = 256, H = 8); per-launch averages; separate rocprofv3 passes per counter set.\n")
-        kt = {r["Name"].split("(")[0]: r for r in one(os.path.join(src, "att2_kt")) if "disgat" in r["Name"]}
+        kt = {kname_of(r["Name"]): r for r in one(os.path.join(src, "att2_kt")) if "disgat" in r["Name"]}
         vals = {}
         for sub in ("sq1", "sq2", "fetch", "write"):
             for k, cs in counters(os.path.join(src, f"att2_{sub}")).items():
@@ -159,7 +184,7 @@ def main(src, dst):
                     for r in csv.DictReader(open(f)):
                         if "disgat" not in r["Kernel_Name"]:
                             continue
-                        k = (r["Kernel_Name"].split("(")[0], int(r["Grid_Size"]))
+                        k = (kname_of(r["Kernel_Name"]), int(r["Grid_Size"]))
                         vals.setdefault(k, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
                         if sub == "fetch":
                             durs.setdefault(k, []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
