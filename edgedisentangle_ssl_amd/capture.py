@@ -62,11 +62,11 @@ def capture_get_em(encoder, x, adj, fusers):
 
 # ---------------------------------------------------------------------------------------------------------------
 # Whole train_steps as HIP graphs.  On Cora / chameleon a train_step is ~400 launches of a few microseconds each
-# behind ~7 ms of Python + autograd-engine work; replayed from a graph, the host does three things per step: one
-# binomial draw per pair list (written into a device scalar), the replay call, and the bookkeeping of step counts.
+# behind ~7 ms of Python + autograd-engine work; replayed from a graph, the host does two things per step: the replay
+# call and the bookkeeping of step counts (the pair samplers' generator state lives on the device: csrc/pair_sample.hip).
 # What makes a step replayable:
 #   * pair lists of FIXED capacity, sampled on the device with their valid length on the device
-#     (sampling.StaticSampler; padding carries label -1, which disgat_pair_loss / _bwd skip);
+#     (sampling.PairSampler.sample_static; padding carries label -1, which disgat_pair_loss / _bwd skip);
 #   * backward segment structures built without reading sizes back (ops_bwd._segments_static);
 #   * attention-dropout seeds = a per-call-site constant + a device counter the step advances (layers.StepSeed);
 #   * Adam's step counts on the device (optim.DeviceStepAdam / disgat_adam_multi_dev).

@@ -49,7 +49,7 @@ def load_model(encoder, args, root="."):
 def reseed_rank(seed, rank):
     """Sharded runs: parameter initialisation and utils.split() must draw the SAME numbers on every rank (replicated
     parameters, global index sets) and have done so by now; from here on every rank needs its OWN streams - the pair
-    sampler (device randint / randperm + the host binomial), the input dropout and the in-kernel attention-dropout seed
+    sampler (sampling.PairSampler takes its seed from torch's CPU generator at first use), the input dropout and the in-kernel attention-dropout seed
     (taken from torch's CPU generator, layers.disga_heads) would otherwise repeat the same (local row, column)
     negatives and the same per-edge mask on every equal-size shard, and the union over ranks would not be the unsharded
     Bernoulli(3 rho) sample sampling.py promises."""

@@ -7,11 +7,11 @@ trainer.py:35-80: same class names, constructor signature (args, model, weight),
 side of the hot path:
   * the reference samples training pairs through dense N x N masks (pretrainer.py:683-707,
     524-576); here the same distribution (Bernoulli(3*rho) over all entries united with a third
-    of the positives, row-major order) is drawn in O(E) on the device (sampling.py);
+    of the positives, row-major order) is drawn in O(output) work by kernels of the library (sampling.py, csrc/pair_sample.hip);
   * `loss(...)` exposes the forward + loss part of train_step on pre-sampled pairs (what bench.py
     times); train_step = sample + loss + backward + optimiser steps as in the reference;
   * train_step returns its log values as 0-d DEVICE tensors (the reference calls .item() per step): nothing in a step
-    waits for the GPU except the sampler's output sizes; utils.resolve_logs() turns a dict of them into floats with
+    waits for the GPU except the sampled lists' lengths (one read per list; none on the captured path); utils.resolve_logs() turns a dict of them into floats with
     one transfer (main.run does that once per epoch).
 """
 import torch
@@ -54,7 +54,7 @@ def _graph_sampler(graph):
 def _pair_loss_value(base, h_lo, h_hi, labels, graph):
     """(loss, neg_w, m) from the HIP partial sums; on a sharded graph sums and pair count are all-reduced (global loss)."""
     acc = ops.pair_loss_sums(base, h_lo, h_hi, labels)
-    count = getattr(labels, "_disgat_count", None)      # fixed-capacity list (sampling.StaticSampler): its valid length, on the device
+    count = getattr(labels, "_disgat_count", None)      # fixed-capacity list (sampling.PairSampler.sample_static): its valid length, on the device
     if count is None:
         count = acc.new_full((1,), float(labels.shape[0]))                 # fill kernel: stays graph-capturable
     acc = torch.cat([acc, count.reshape(1).to(acc.dtype)])
@@ -150,7 +150,7 @@ class Trainer(object):
         return self.constrain_layer == 0 or self.constrain_layer == i       # pretrainer.py:597, 728
 
     # ---- the same train_step as a HIP graph (capture.StaticStep): subclasses give the host half (_static_host: the
-    # sampler's binomial draws) and the device half (_static_device: sample + forward + loss + backward + Adam).
+    # pair samplers' seeds at first use) and the device half (_static_device: sample + forward + loss + backward + Adam).
     def _static_finish(self, adam, loss, always_step=False):
         (loss * self.loss_weight).backward()
         ops_bwd.clear_segment_cache()
