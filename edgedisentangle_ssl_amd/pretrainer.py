@@ -225,7 +225,8 @@ class SupEdgeTrainer(Trainer):
         return graph_of(adj)
 
     def sample_train(self, gt):
-        idx, lab = self._static_sampler(gt).sample()
+        smp = self._static_sampler(gt)
+        idx, lab = smp.sample_padded() if sampling.PADDED_LISTS else smp.sample()
         return lab, [idx]
 
     def inference(self, data, sparse_edge_index=None):
@@ -302,7 +303,7 @@ class GeneratedEdgeTrainer(Trainer):
     def sample_train(self):
         labs, idxs = [], []
         for smp in self._static_samplers():
-            idx, lab = smp.sample()
+            idx, lab = smp.sample_padded() if sampling.PADDED_LISTS else smp.sample()
             labs.append(lab)
             idxs.append(idx)
         return labs, idxs

@@ -24,6 +24,12 @@ from . import _lib
 
 PCAP, RCAP, RMEAN = 256, 256, 96          # include/disgat_hip.h: DISGAT_SAMPLE_PCAP / _RCAP / _RMEAN
 _I64_MAX = (1 << 63) - 1
+# The trainers' eager train_step()s (pretrainer.*.sample_train) take their lists at FIXED capacity (sample_padded: the
+# valid length stays on the device, the tail is padding the loss kernels skip) instead of exact length: every buffer sized by
+# the list - scores, sign records (17 GB at 1M nodes), gradients - then has the same size every step and comes back from the
+# caching allocator, and the step has no host read at all.  With exact lengths the sizes wander by a few MB from step to step
+# and a step occasionally pays for fresh device allocations of tens of GB (a bench.py run read 1 392 ms for a 1 024 ms step).
+PADDED_LISTS = True
 
 
 def flat_edges(graph):
@@ -146,6 +152,13 @@ class PairSampler:
         lab = torch.empty(m, dtype=torch.float32, device=self.device)
         self._emit(m, idx, lab, 0)
         idx._disgat_checked = (self.n_rows, self.n_cols, idx._version)    # in range by construction (ops.check_pairs): no round trip
+        return idx, lab
+
+    def sample_padded(self):
+        """sample_static() for steps that are NOT replayed from a graph: the same fixed-capacity list, without the mark that
+        sends the backward to the fixed-capacity segment tables (an eager step may read sizes back and sort its work items)."""
+        idx, lab = self.sample_static()
+        del idx._disgat_static
         return idx, lab
 
     def sample_static(self):

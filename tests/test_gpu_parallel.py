@@ -182,9 +182,11 @@ def _train_worker(rank, world, port, q, golden_dir):
         dis_t.get_label_all(xl, dg, lab)
         lab_s, idx_s = sup_t.sample_train(dg)
         assert int(idx_s[0][0].max()) < dg.n and int(idx_s[0][1].max()) < n and int(idx_s[0][1].max()) >= dg.n
-        flat = (idx_s[0][0] + lo) * n + idx_s[0][1]
+        cnt = int(lab_s._disgat_count)                      # fixed-capacity list: valid prefix, then padding (label -1)
+        assert 0 < cnt <= lab_s.shape[0] and bool((lab_s[cnt:] == -1).all())
+        flat = (idx_s[0][0][:cnt] + lo) * n + idx_s[0][1][:cnt]
         pos = g.row * n + g.col.long()
-        assert torch.equal(lab_s, torch.isin(flat, pos).float())
+        assert torch.equal(lab_s[:cnt], torch.isin(flat, pos).float())
         logs = {}
         logs.update(sup_t.train_step((xl, dg)))
         logs.update(dis_t.train_step((xl, dg)))

@@ -19,6 +19,9 @@ ap.add_argument("--att", type=int, default=3)
 ap.add_argument("--gnn_type", default="AT")
 ap.add_argument("--dropout", type=float, default=0.1)
 ap.add_argument("--skip-unused", action="store_true", help="DISGAT.skip_unused as main.run sets it (no discarded layer-2 aggregation)")
+ap.add_argument("--sampled", choices=("none", "exact", "padded"), default="none",
+                help="also time the trainers' own train_step()s: lists drawn every step, exact length or fixed capacity (padded)")
+ap.add_argument("--iters", type=int, default=3)
 a = ap.parse_args()
 sys.argv = ["bench.py", "--nodes", str(a.nodes), "--edges", str(a.edges), "--feat", str(a.feat), "--att", str(a.att),
             "--gnn_type", a.gnn_type]
@@ -64,11 +67,20 @@ def train():
     return out
 
 
-for name, fn in (("forward only (eval)", fwd_only), ("train (fwd+bwd+Adam, dropout %.2f)" % a.dropout, train)):
+cases = [("forward only (eval)", fwd_only), ("train (fwd+bwd+Adam, dropout %.2f)" % a.dropout, train)]
+if a.sampled != "none":
+    from edgedisentangle_ssl_amd import sampling, synth
+    dis.get_label_all(x, graph, synth.node_labels(graph.n, dev))
+    sampling.PADDED_LISTS = a.sampled == "padded"
+
+    def train_sampled():
+        return [sup.train_step(data, graph), dis.train_step(data), dif.train_step(data)]
+    cases.append((f"train_step()s with sampled lists ({a.sampled})", train_sampled))
+for name, fn in cases:
     fn()
     torch.cuda.synchronize()
     t = time.perf_counter()
-    n = 3
+    n = a.iters
     for _ in range(n):
         r = fn()
     torch.cuda.synchronize()
