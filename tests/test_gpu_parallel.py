@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q, golden_dir):
+def _worker(rank, world, port, q, golden_dir, configs=(("AT", 3), ("SAGE", 1), ("GCN", 2))):
     try:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
@@ -44,7 +44,7 @@ def _worker(rank, world, port, q, golden_dir):
         sup = ic.sample_pairs(61, n, pos, "sup")
         ho = ic.sample_pairs(62, n, homo, "homo")
         he = ic.sample_pairs(63, n, het, "het")
-        for gnn, att in (("AT", 3), ("SAGE", 1), ("GCN", 2)):
+        for gnn, att in configs:
             a, enc, _ = build(gnn, att, 8, 64, 64, 200 + att, dev)
             sup_t, dis_t, dif_t = _trainers(a, enc, 200 + att, dev)
             fus = [sup_t.fuse1, sup_t.fuse2]
@@ -149,6 +149,12 @@ def _run_ranks(target, world, args, timeout=500):
 
 def test_sharded_equals_unsharded_two_ranks_one_gpu(golden_dir):
     _run_ranks(_worker, 2, (golden_dir,))
+
+
+def test_sharded_equals_unsharded_four_ranks_one_gpu(golden_dir):
+    """Four ragged row ranges (2708 rows -> 677 each) on the real kernels: the sliced gather's four slices, the halo
+    tables and the adjoint's reduce-scatter all see more than one peer."""
+    _run_ranks(_worker, 4, (golden_dir, (("AT", 3), ("SAGE", 1))))
 
 
 def _train_worker(rank, world, port, q, golden_dir):
