@@ -840,35 +840,70 @@ __global__ __launch_bounds__(256) void wamax_kernel(const float* __restrict__ W,
   block_atomic_max(m, out);
 }
 
+// One element of the split: position i of the [batch][N][K] output order (coalesced plane writes), scale s.
+__device__ __forceinline__ void wsplit_one(const float* __restrict__ W, int64_t sb, int64_t sk, int64_t sn, int K, int N,
+                                           int64_t kn, int64_t i, float s, uint16_t* __restrict__ planes, int frag) {
+  const int64_t b = i / kn, r = i - b * kn;
+  const int64_t n = r / K, k = r - n * K;
+  const float t = W[b * sb + k * sk + n * sn] * s;
+  const _Float16 h = (_Float16)t;
+  const _Float16 l = (_Float16)((t - (float)h) * 2048.f);
+  // K <= 256 (operands of the A-stationary kernel): fragment-major - the 16 x 32 block of (n-tile, k-step) is stored
+  // in MFMA lane order (lane = 16*(k%32/8) + n%16, 8 halfs each), so a wave's fragment load is one contiguous KB
+  int64_t o = r;
+  if (frag == 1) {
+    o = ((((n >> 4) * (K >> 5) + (k >> 5)) * 64 + (((k & 31) >> 3) << 4) + (n & 15)) << 3) + (k & 7);
+  } else if (frag == 2) {
+    // DMA-tiled (disgat_gemm_planes): per (256-column step, k-step) one 16 KB block that IS the LDS image of the weight
+    // tile - LDS row rho holds weight row wperm(rho) (gemm_planes.hip), 16-byte chunk c of it at slot c ^ ((rho >> 1) & 3)
+    // - so a DMA piece (16 LDS rows) is 1 KB of consecutive memory: 8 full 128-byte lines instead of 16 half lines
+    const int64_t ns = n >> 8, nl = n & 255, x = nl & 31;
+    const int64_t rho = (nl & ~31) + (((x >> 2) & 1) << 4) + ((x >> 3) << 2) + (x & 3);
+    const int64_t t2 = k >> 5, c = ((k & 31) >> 3) ^ ((rho >> 1) & 3);
+    o = (((ns * (K >> 5) + t2) * 256 + rho) << 5) + (c << 3) + (k & 7);
+  }
+  planes[(b * 2 + 0) * kn + o] = *reinterpret_cast<const uint16_t*>(&h);
+  planes[(b * 2 + 1) * kn + o] = *reinterpret_cast<const uint16_t*>(&l);
+}
+
 __global__ __launch_bounds__(256) void wsplit_kernel(const float* __restrict__ W, int64_t sb, int64_t sk, int64_t sn, int K,
                                                      int N, int64_t total, const float* __restrict__ amax,
                                                      uint16_t* __restrict__ planes, float* __restrict__ scale_out, int frag) {
   const float s = f16_scale(*amax);
   if (blockIdx.x == 0 && threadIdx.x == 0) *scale_out = s;
   const int64_t kn = (int64_t)K * N;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256)
+    wsplit_one(W, sb, sk, sn, K, N, kn, i, s, planes, frag);
+}
+
+// The same preparation of a SMALL weight (<= WPREP_SMALL elements: the layers of the bundled graphs, whose train_steps
+// are launch-bound) in ONE launch: every block reduces max |W| over the whole weight itself (<= 512 KB, from L2), so
+// there is no zeroed accumulator, no atomic and no second kernel; then it splits its own share.  Same max, same scale,
+// same planes as the two-launch form, bit for bit.
+constexpr int64_t WPREP_SMALL = 131072;
+__global__ __launch_bounds__(256) void wprep_small_kernel(const float* __restrict__ W, int64_t sb, int64_t sk, int64_t sn, int K,
+                                                          int N, int64_t total, float* __restrict__ amax_scale,
+                                                          uint16_t* __restrict__ planes, int frag) {
+  __shared__ uint32_t wave_max[4];
+  uint32_t m = 0u;
+  const int64_t kn = (int64_t)K * N;
+  for (int64_t i = threadIdx.x; i < total; i += 256) {
     const int64_t b = i / kn, r = i - b * kn;
-    const int64_t n = r / K, k = r - n * K;                       // output order [n][k]: coalesced plane writes
-    const float t = W[b * sb + k * sk + n * sn] * s;
-    const _Float16 h = (_Float16)t;
-    const _Float16 l = (_Float16)((t - (float)h) * 2048.f);
-    // K <= 256 (operands of the A-stationary kernel): fragment-major - the 16 x 32 block of (n-tile, k-step) is stored
-    // in MFMA lane order (lane = 16*(k%32/8) + n%16, 8 halfs each), so a wave's fragment load is one contiguous KB
-    int64_t o = r;
-    if (frag == 1) {
-      o = ((((n >> 4) * (K >> 5) + (k >> 5)) * 64 + (((k & 31) >> 3) << 4) + (n & 15)) << 3) + (k & 7);
-    } else if (frag == 2) {
-      // DMA-tiled (disgat_gemm_planes): per (256-column step, k-step) one 16 KB block that IS the LDS image of the weight
-      // tile - LDS row rho holds weight row wperm(rho) (gemm_planes.hip), 16-byte chunk c of it at slot c ^ ((rho >> 1) & 3)
-      // - so a DMA piece (16 LDS rows) is 1 KB of consecutive memory: 8 full 128-byte lines instead of 16 half lines
-      const int64_t ns = n >> 8, nl = n & 255, x = nl & 31;
-      const int64_t rho = (nl & ~31) + (((x >> 2) & 1) << 4) + ((x >> 3) << 2) + (x & 3);
-      const int64_t t = k >> 5, c = ((k & 31) >> 3) ^ ((rho >> 1) & 3);
-      o = (((ns * (K >> 5) + t) * 256 + rho) << 5) + (c << 3) + (k & 7);
-    }
-    planes[(b * 2 + 0) * kn + o] = *reinterpret_cast<const uint16_t*>(&h);
-    planes[(b * 2 + 1) * kn + o] = *reinterpret_cast<const uint16_t*>(&l);
+    const int64_t k = r / N, n = r - k * N;
+    m = max(m, __float_as_uint(fabsf(W[b * sb + k * sk + n * sn])));
   }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+  if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3]));
+  const float s = f16_scale(__uint_as_float(m));
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    amax_scale[0] = __uint_as_float(m);
+    amax_scale[1] = s;
+  }
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256)
+    wsplit_one(W, sb, sk, sn, K, N, kn, i, s, planes, frag);
 }
 
 // max |A| over a (batched, strided) fp32 operand into *out (a device float the caller zeroed): the bit pattern
@@ -970,6 +1005,12 @@ extern "C" int disgat_gemm_split(const float* A, int64_t lda, int64_t a_batch_st
 namespace disgat {
 static int split_f16_impl(const float* W, int64_t stride_b, int64_t stride_k, int64_t stride_n, int K, int N, int batch,
                           uint16_t* planes, float* amax_scale, int frag, hipStream_t st) {
+  if ((int64_t)batch * K * N <= WPREP_SMALL) {
+    const int64_t tot = (int64_t)batch * K * N;
+    hipLaunchKernelGGL(wprep_small_kernel, dim3((unsigned)(tot / 4096 + 1)), dim3(256), 0, st, W, stride_b, stride_k, stride_n,
+                       K, N, tot, amax_scale, planes, frag);
+    return check_launch("wprep_small_kernel");
+  }
   const hipError_t e = hipMemsetAsync(amax_scale, 0, 2 * sizeof(float), st);
   if (e != hipSuccess) return fail((int)e, "split_f16: memset failed: %s", hipGetErrorString(e));
   const int64_t total = (int64_t)batch * K * N;

@@ -181,6 +181,35 @@ def clear_weight_cache(module):
         m.__dict__.pop("_disgat_memo", None)
 
 
+class _PackAtt3(torch.autograd.Function):
+    """The H heads' att-3 parameters W_h [2 F_in, F_out], a_h [F_out, 1] as the operands of the fused pass:
+    wt, wb [F_in, H*F_out] (top / bottom half of every W_h side by side) and a flat a_vec [H*F_out].
+    Forward: the W_h are stacked along dim 1 - [2 F_in, H, F_out] IS [wt; wb], so both are row ranges of one buffer
+    (one launch; the stack / slice / permute / reshape chain was 3).  Backward: the two operand gradients go back into
+    one [H, 2 F_in, F_out] buffer whose slabs are the per-head gradients (autograd's own route through the slices
+    zero-filled and copied a full-size tensor per slice: 7 launches per layer of a launch-bound step)."""
+
+    @staticmethod
+    def forward(ctx, f_in, *params):
+        H = len(params) // 2
+        wcat = torch.stack(params[:H], dim=1)                       # [2 F_in, H, F_out]
+        f_out = wcat.shape[2]
+        ctx.dims = (f_in, H, f_out)
+        a_vec = torch.stack(params[H:]).reshape(-1)                 # [H, F_out, 1] -> flat
+        return wcat[:f_in].view(f_in, H * f_out), wcat[f_in:].view(f_in, H * f_out), a_vec
+
+    @staticmethod
+    def backward(ctx, g_wt, g_wb, g_a):
+        f_in, H, f_out = ctx.dims
+        g_w = [None] * H
+        if g_wt is not None or g_wb is not None:
+            halves = [(g if g is not None else torch.zeros_like(o)).reshape(f_in, H, f_out).permute(1, 0, 2)
+                      for g, o in ((g_wt, g_wb), (g_wb, g_wt))]
+            g_w = list(torch.cat(halves, dim=1).unbind(0))          # [H, 2 F_in, F_out]: slab h is head h's gradient
+        g_as = [None] * H if g_a is None else list(g_a.reshape(H, f_out, 1).unbind(0))
+        return (None, *g_w, *g_as)
+
+
 def _pack_score_operands(layers, x, x_all, att, H, Hp, f_in, f_out, fp, am=None, cols=None):
     """Dense, differentiable (torch ops -> MFMA GEMMs) preparation of the per-node score operands.
     x: the rows this process owns; x_all: every node a column index can name (== x unsharded).
@@ -226,10 +255,7 @@ def _pack_score_operands(layers, x, x_all, att, H, Hp, f_in, f_out, fp, am=None,
         if Hp == H and fp == fw == f_out:
             # no padding anywhere (the common case): one stack + two strided copies instead of 3 H pad / cat kernels -
             # on Cora-sized graphs the per-head form was a third of a train_step's launches
-            wst = torch.stack([l.W for l in layers])                                     # [H, 2 F_in, F_out]
-            wt = wst[:, :f_in].permute(1, 0, 2).reshape(f_in, H * f_out)
-            wb = wst[:, f_in:].permute(1, 0, 2).reshape(f_in, H * f_out)
-            a_vec = torch.stack([l.a for l in layers]).reshape(-1)       # [H, F_out, 1] -> flat: no per-head select in the graph
+            wt, wb, a_vec = _PackAtt3.apply(f_in, *[l.W for l in layers], *[l.a for l in layers])
             return wt, wb, a_vec, ops_gemm.presplit(wt), ops_gemm.presplit(wb)
         tops = [F.pad(l.W[:f_in, c0:c1], (0, fp - fw)) for l in layers] + [x.new_zeros(f_in, fp)] * (Hp - H)
         bots = [F.pad(l.W[f_in:, c0:c1], (0, fp - fw)) for l in layers] + [x.new_zeros(f_in, fp)] * (Hp - H)

@@ -221,6 +221,49 @@ def pair_loss_sums(aux, h_lo, h_hi, labels):
     return acc
 
 
+class ClsLoss(torch.autograd.Function):
+    """disgat_cls_loss: log_softmax + NLL + accuracy of the rows of two splits in one pass over `logits` [N, C].
+
+    code: int32 [N] row codes (-1 = in no split, else label + (split << 16)), or None with label_mod = the DifHead form
+    (every row in split 0, label = row % label_mod).  div0 / div1: the splits' (global) sizes.
+    Returns (loss, logp, res): loss = a 0-d fp32 tensor, split 0's NLL sum / div0 - the only differentiable output;
+    logp [N, C]; res float64 [4] = (NLL_0 / div0, correct_0 / div0, NLL_1 / div1, correct_1 / div1)."""
+
+    @staticmethod
+    def forward(ctx, logits, code, label_mod, div0, div1):
+        _check(logits, "logits")
+        if logits.dim() != 2 or logits.stride(1) != 1:
+            raise RuntimeError("cls_loss: logits must be [N, C] with unit inner stride")
+        n, c = logits.shape
+        if code is not None and (code.dtype != torch.int32 or not code.is_cuda or code.shape != (n,) or not code.is_contiguous()):
+            raise RuntimeError("cls_loss: row codes must be a contiguous int32 device tensor [N]")
+        logp = torch.empty((n, c), dtype=torch.float32, device=logits.device)
+        res = torch.empty(4, dtype=torch.float64, device=logits.device)
+        loss = torch.empty((), dtype=torch.float32, device=logits.device)
+        part = torch.empty((1024, 4), dtype=torch.float64, device=logits.device) if n > 8192 else None
+        _lib.call("disgat_cls_loss", logits.data_ptr(), logits.stride(0), _ptr(code), int(label_mod), n, c, float(div0), float(div1),
+                  logp.data_ptr(), logp.stride(0), _ptr(part), loss.data_ptr(), res.data_ptr(), _stream())
+        ctx.save_for_backward(logp, code)
+        ctx.cfg = (int(label_mod), float(div0))
+        ctx.mark_non_differentiable(logp, res)
+        return loss, logp, res
+
+    @staticmethod
+    def backward(ctx, g, _g_logp, _g_res):
+        logp, code = ctx.saved_tensors
+        label_mod, div0 = ctx.cfg
+        n, c = logp.shape
+        gx = torch.empty_like(logp)
+        g = g.reshape(1).contiguous().float()
+        _lib.call("disgat_cls_loss_bwd", logp.data_ptr(), logp.stride(0), _ptr(code), label_mod, n, c, g.data_ptr(), div0,
+                  gx.data_ptr(), gx.stride(0), _stream())
+        return gx, None, None, None, None
+
+
+def cls_loss(logits, code, label_mod, div0, div1=1.0):
+    return ClsLoss.apply(logits, code, label_mod, div0, div1)
+
+
 class EdgePass(torch.autograd.Function):
     """Differentiable wrapper of edge_forward.  Non-tensor config travels in `cfg`; e_in: optional [H,E] partial
     scores (its gradient is the total score gradient)."""

@@ -416,12 +416,12 @@ class DifHeadTrainer(Trainer):
                 for m in mods[2:]:
                     # hidden -> nhead logits on N * nhead rows: 1 KB read per 32 B written (ops_gemm.skinny_linear)
                     t = ops_gemm.skinny_linear(t, m) if isinstance(m, torch.nn.Linear) and ops_gemm.skinny_ok(t, m) else m(t)
-                diag = F.log_softmax(t, dim=1).view(-1, nh, t.shape[1]).diagonal(dim1=1, dim2=2)   # logp[n, i, i]
-                if sharded:
-                    loc = -diag.sum() / g.n_global
-                    term = loc + (parallel.all_reduce_sum(loc.detach().clone(), g) - loc.detach())
-                else:
-                    term = -diag.mean(0).sum()
+                # sum over heads i of NLL(log_softmax(t[(n, i)]), i), mean over nodes: row (n, i) of t carries label i - one
+                # pass over the logits (ops.cls_loss) instead of log_softmax / diagonal / mean / neg and their backwards
+                if t.stride(1) != 1:
+                    t = t.contiguous()
+                loc = ops.cls_loss(t, None, nh, g.n_global if sharded else t.shape[0] // nh)[0]
+                term = loc + (parallel.all_reduce_sum(loc.detach().clone(), g) - loc.detach()) if sharded else loc
                 loss = term if loss is None else loss + term
                 continue
             else:

@@ -3,7 +3,7 @@ trainer.py:16-32, 150-223, 297-320).  A caller of the hot path, kept for drop-in
 import torch
 import torch.nn.functional as F
 
-from . import parallel
+from . import ops, parallel
 from .graph import graph_of
 from .models import MLP
 from .pretrainer import Trainer, make_adam
@@ -81,6 +81,33 @@ class ClsTrainer(Trainer):
             return local + (tot[0].to(local.dtype) - local.detach()), tot[1] / n_glob
         return nll_sum / n_glob, correct / n_glob
 
+    def _row_codes(self, labels, graph):
+        """int32 code per row this process owns for ops.cls_loss: label of a training node, label + 65536 of a validation
+        node, -1 otherwise.  Built once per (labels, graph): the splits never change (trainer.py:47)."""
+        hit = self.__dict__.get("_cls_codes")
+        if hit is not None and hit[0] is labels and hit[1] is graph and hit[2] == labels._version:
+            return hit[3]
+        code = torch.full((graph.n,), -1, dtype=torch.int32, device=labels.device)
+        for split, idx in ((1, self.idx_val), (0, self.idx_train)):
+            loc, glob, _ = self._local(idx, graph)
+            code[loc] = labels[glob].to(torch.int32) + (split << 16)
+        self._cls_codes = (labels, graph, labels._version, code)
+        return code
+
+    def _loss_and_logs(self, feature, adj, labels, graph):
+        """Forward + the step's four log numbers from ONE pass over the logits (ops.cls_loss: log_softmax, NLL and accuracy
+        of the training split, the same on the validation split - trainer.py:186-199, 209-212 read them off the same
+        pre-step output).  Returns (loss with graph, acc_train, loss_val, acc_val, log-probabilities)."""
+        logits = self.classifier(self.get_em(feature, adj))
+        n_tr, n_va = max(1, int(self.idx_train.shape[0])), max(1, int(self.idx_val.shape[0]))
+        loss, logp, res = ops.cls_loss(logits, self._row_codes(labels, graph), 0, n_tr, n_va)
+        if isinstance(graph, parallel.DistGraph) and graph.world > 1:
+            # every rank summed over the nodes it owns: the value is the sum over ranks, the gradient this rank's share
+            tot = res.clone()
+            parallel.all_reduce_sum(tot, graph)
+            return loss + (tot[0].to(loss.dtype) - loss.detach()), tot[1], tot[2], tot[3], logp
+        return loss, res[1], res[2], res[3], logp
+
     def train_step(self, data, labels, epoch):
         """trainer.py:178-223.  Log values are 0-d device tensors (utils.resolve_logs); the sklearn ROC / macro-F1 of
         the validation split, which the reference recomputes on the host every step for its log line only, are
@@ -89,15 +116,12 @@ class ClsTrainer(Trainer):
         feature, adj = data
         graph = graph_of(adj)
         sharded = isinstance(graph, parallel.DistGraph) and graph.world > 1
-        output = self.classifier(self.get_em(feature, adj), cls=True)
-        loss_log, acc_train = self._nll_acc(output, labels, self.idx_train, graph)
+        loss_log, acc_train, loss_val, acc_val, output = self._loss_and_logs(feature, adj, labels, graph)
         reg_log = self.reg_fuser()
         loss = loss_log
         if self.args.reg:          # the L1 term is replicated on every rank: each contributes 1/world of its gradient
             loss = loss_log + (reg_log / graph.world if sharded else reg_log)
         self._finish_step(loss, graph, always_step=True)
-        with torch.no_grad():
-            loss_val, acc_val = self._nll_acc(output.detach(), labels, self.idx_val, graph)
         log = {"loss_train": loss_log.detach(), "acc_train": acc_train, "loss_reg": reg_log.detach(),
                "loss_val": loss_val, "acc_val": acc_val}
         if self.full_metrics and not sharded:
@@ -107,13 +131,10 @@ class ClsTrainer(Trainer):
     def _static_device(self, adam, data, labels, epoch=0):
         feature, adj = data
         graph = graph_of(adj)
-        output = self.classifier(self.get_em(feature, adj), cls=True)
-        loss_log, acc_train = self._nll_acc(output, labels, self.idx_train, graph)
+        loss_log, acc_train, loss_val, acc_val, _ = self._loss_and_logs(feature, adj, labels, graph)
         reg_log = self.reg_fuser()
         loss = loss_log + reg_log if self.args.reg else loss_log
         self._static_finish(adam, loss, always_step=True)
-        with torch.no_grad():
-            loss_val, acc_val = self._nll_acc(output.detach(), labels, self.idx_val, graph)
         return {"loss_train": loss_log.detach(), "acc_train": acc_train, "loss_reg": reg_log.detach(),
                 "loss_val": loss_val, "acc_val": acc_val}
 

@@ -25,6 +25,8 @@
  *                       836; trainer.py:200).  Gather-only segment passes, see csrc/edge_bwd.hip.
  *  disgat_pair_loss     sigmoid(sum of heads) + utils.adj_mse_loss partial sums
  *                       (pretrainer.py:727-739, 612-627; utils.py:287-298).
+ *  disgat_cls_loss      F.log_softmax + F.nll_loss + utils.accuracy on the train and validation splits
+ *                       (trainer.py:186-199) and DifHead's NLL against the head index (pretrainer.py:819-832).
  *  disgat_gemm_f16x3,   the dense contractions of the path - torch.mm / nn.Linear at layers.py:350, 363, 376,
  *  disgat_gemm_split,   398, 110, 39, 905 and models.py:538 (ATen fp32 GEMM) - as fp32-accurate GEMMs on the
  *  disgat_split_f16,    16-bit matrix cores (operand splitting), with the bias / additive / ELU (layers.py:508)
@@ -77,7 +79,7 @@ extern "C" {
 
 typedef void* disgat_stream_t; /* hipStream_t */
 
-int disgat_abi_version(void);          /* 4 in this revision; changes with any launcher's argument list */
+int disgat_abi_version(void);          /* 5 in this revision; changes with any launcher's argument list */
 const char* disgat_last_error(void);
 
 /* Fused score -> sigmoid -> row softmax -> aggregation for all H heads of one layer.
@@ -123,7 +125,28 @@ int disgat_aux_score(int att, const int64_t* pair_rows, const int64_t* pair_cols
 int disgat_pair_loss(const float* aux, int64_t M, int h_lo, int h_hi, const float* labels,
                      double* acc, double* block_partials, disgat_stream_t stream);
 
+/* Classification loss in one pass over logits [n_rows][n_cls] (row stride ld): per row log_softmax (written to logp when
+ * non-NULL, row stride ld_logp), and over the rows of split s = 0, 1 the sums of -logp[label] and of (argmax == label).
+ *   row_code    int32 [n_rows]: -1 = the row is in no split, else label + (split << 16); NULL: every row is in split 0
+ *               with label (row % label_mod) - DifHead's (node, head) rows
+ *   div0, div1  the divisors of split 0 / 1 (the GLOBAL split sizes: on a row shard the caller adds the ranks' results)
+ *   loss        float [1]  = NLL sum of split 0 / div0, the value the backward differentiates
+ *   res         double [4] = {NLL_0 / div0, correct_0 / div0, NLL_1 / div1, correct_1 / div1}
+ *   block_partials  scratch of DISGAT_CLS_LOSS_MAX_BLOCKS x 4 doubles, needed above DISGAT_CLS_LOSS_ONE_BLOCK rows (per-block
+ *               sums added in block order by a second tiny launch; up to that size one block does everything in one launch)
+ * Sums are doubles taken in a fixed order: run-to-run deterministic. */
+#define DISGAT_CLS_LOSS_MAX_BLOCKS 1024
+#define DISGAT_CLS_LOSS_ONE_BLOCK 8192
+int disgat_cls_loss(const float* logits, int64_t ld, const int32_t* row_code, int label_mod, int64_t n_rows, int n_cls,
+                    double div0, double div1, float* logp, int64_t ld_logp, double* block_partials, float* loss,
+                    double* res, disgat_stream_t stream);
+
 /* ---- backward -------------------------------------------------------------------------- */
+
+/* Gradient of disgat_cls_loss's `loss` w.r.t. the logits from the saved logp: rows of split 0 get
+ * (exp(logp) - onehot(label)) * g[0] / div0, every other row zeros (g: the upstream gradient, one device float). */
+int disgat_cls_loss_bwd(const float* logp, int64_t ld_logp, const int32_t* row_code, int label_mod, int64_t n_rows,
+                        int n_cls, const float* g, double div0, float* grad_logits, int64_t ld_grad, disgat_stream_t stream);
 
 /* Gradient of that loss w.r.t. the raw scores: g[h][m] = coef[labels[m] != 0 ? 0 : 1] * 2 (p - t) p (1 - p) for h in
  * [h_lo, h_hi), 0 for the other of the H rows; coef = 2 device floats (upstream gradient x class weight / M).

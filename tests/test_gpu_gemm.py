@@ -155,11 +155,17 @@ def test_weight_split_reconstructs_strided_and_expanded_weights():
     from edgedisentangle_ssl_amd import ops_gemm
     g = torch.Generator(device="cuda").manual_seed(5)
     base = torch.randn(300, 200, device="cuda", generator=g) * 3.0
-    cases = [base, base.t(), base[:, 40:168], base[::2, :].t().unsqueeze(0).expand(4, 200, 150)]
+    big = torch.randn(700, 520, device="cuda", generator=g) * 0.02     # > 131072 elements: the two-launch form
+    cases = [base, base.t(), base[:, 40:168], base[::2, :].t().unsqueeze(0).expand(4, 200, 150), big, big.t()[:, 100:]]
     for w in cases:
         planes, s = ops_gemm.split_weight_f16(w)
         w3 = w if w.dim() == 3 else w.unsqueeze(0)
         p = planes.view(torch.float16).float()                       # [hb, 2, N, K]
+        # the one-launch form (small weights) and the two-launch form store the same planes: exactly these
+        t = (w3 * s).transpose(1, 2)
+        h = t.half()
+        assert torch.equal(planes.view(torch.float16)[:, 0], h)
+        assert torch.equal(planes.view(torch.float16)[:, 1], ((t - h.float()) * 2048.0).half())
         rec = (p[:, 0] + p[:, 1] / 2048.0).transpose(1, 2)            # [hb, K, N]
         ref = w3 * s
         assert float(s) == 2.0 ** round(float(torch.log2(s)))        # a power of two

@@ -46,7 +46,8 @@ for n, (tr, a) in kept.items():
     st = tr.static_step()
     st.run_eager(*a)
     torch.cuda.synchronize()
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True,
+                 experimental_config=torch._C._profiler._ExperimentalConfig(verbose=True)) as prof:
         st.run_eager(*a)
         torch.cuda.synchronize()
     # launches per CPU op: a device event is linked to the runtime call that made it, whose parent chain holds the op
@@ -73,6 +74,19 @@ for n, (tr, a) in kept.items():
         s = site_of(ev.stack or [])
         by_site[s] += k
         by_site_ops[s][ev.name] += k
+    if os.environ.get("OP_SITES_SEQ") == "1":       # the step as a time-ordered list: op, launches, enclosing ops
+        print(f"\n== {n}: sequence")
+        for ev in sorted(prof.events(), key=lambda e: e.time_range.start):
+            if ev.device_type == torch.autograd.DeviceType.CUDA or not ev.kernels:
+                continue
+            if any(c.kernels for c in ev.cpu_children):
+                continue                                  # report at the innermost op that owns the launches
+            chain, p = [], ev.cpu_parent
+            while p is not None:
+                chain.append(p.name.replace("aten::", ""))
+                p = p.cpu_parent
+            kn = ",".join(k.name.split("(")[0].split("::")[-1][:28] for k in ev.kernels)
+            print(f"   {len(ev.kernels):2d} {ev.name.replace('aten::', ''):28s} <- {' <- '.join(chain[:4]):60s} [{kn}]")
     print(f"\n== {n}: {n_launch} launches attributed")
     for s, c in by_site.most_common(int(os.environ.get("OP_SITES_TOP", 60))):
         ops = ", ".join(f"{o.replace('aten::', '')} x{k}" for o, k in by_site_ops[s].most_common(6))
