@@ -102,9 +102,14 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_rs_kernel(const GemmHArgs G
   const int lane = threadIdx.x & 63;
   const int wave = rfl(threadIdx.x >> 6);
   const int bz = blockIdx.y;
-  const int m0 = blockIdx.x * RS_BM;
+  // G.mt = column splits (launcher): few row blocks (the bundled graphs: 9-80 of them for 256 CUs) share the chunks of a
+  // row block among `ns` workgroups, each with its own copy of the A fragments; 1 at any size that fills the chip by rows
+  const int ns = G.mt;
+  const int mb = ns == 1 ? (int)blockIdx.x : (int)blockIdx.x / ns;
+  const int c_base = ns == 1 ? 0 : ((int)blockIdx.x - mb * ns) * (G.N / RS_CH / ns);
+  const int m0 = mb * RS_BM;
   const int K = KT * 32;
-  const int n_ch = G.N / RS_CH;
+  const int n_ch = G.N / RS_CH / ns;
 
   const float* A = G.A + (int64_t)bz * G.a_bs;
   const uint16_t* Bt = G.Bt + (int64_t)bz * 2 * G.N * K;
@@ -121,10 +126,10 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_rs_kernel(const GemmHArgs G
   const int64_t b_plane = (int64_t)G.N * K;
   // blocks walk the chunks in rotated order: every block streams the same planes from its XCD's L2, and blocks that start
   // together would otherwise ask one L2 channel for the same lines at the same time
-  const int rot = blockIdx.x % n_ch;
+  const int rot = mb % n_ch;
   auto chunk_of = [&](int c) __attribute__((always_inline)) {
     const int cc = (c < n_ch ? c : n_ch - 1) + rot;                 // past the end: the last chunk again (the counts assume an issue per step)
-    return cc >= n_ch ? cc - n_ch : cc;
+    return c_base + (cc >= n_ch ? cc - n_ch : cc);
   };
   auto issue = [&](int c) __attribute__((always_inline)) {
     const int cc = chunk_of(c);
@@ -325,7 +330,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_rs_kernel(const GemmHArgs G
 
 template <int ACT>
 int launch_rs_kt(const GemmHArgs& G, hipStream_t st) {
-  const dim3 grid((unsigned)((G.M + RS_BM - 1) / RS_BM), G.batch);
+  const dim3 grid((unsigned)((G.M + RS_BM - 1) / RS_BM) * G.mt, G.batch);
   auto go = [&](auto fn, int kt) {
     const int lds_bytes = RS_NS * 2 * (2 * kt * 1024);
     static int lds_set[3][9] = {};
@@ -352,6 +357,12 @@ bool gemm_rs_takes(int N, int K) { return (K == 64 || K == 128 || K == 256) && N
 int launch_gemm_f16x3_rs(const GemmHArgs& G0, hipStream_t st) {
   GemmHArgs G = G0;
   G.nt = (RS_DIAG && getenv("DISGAT_RS_DEBUG")) ? atoi(getenv("DISGAT_RS_DEBUG")) : 0;     // (nt is unused by this kernel)
+  // column splits (G.mt, see the kernel): double while the grid stays within the chip's 256 CUs x 2 resident blocks and a
+  // block keeps at least 2 chunks (the ring's prologue requests 3)
+  const int64_t row_blocks = (int64_t)((G.M + RS_BM - 1) / RS_BM) * G.batch;
+  int ns = 1;
+  for (int n_ch = G.N / RS_CH; n_ch % 2 == 0 && n_ch >= 4 && row_blocks * ns * 2 <= 512; n_ch /= 2) ns *= 2;
+  G.mt = ns;
   if (G.act == 1) return launch_rs_kt<1>(G, st);
   if (G.act == 2) return launch_rs_kt<2>(G, st);
   return launch_rs_kt<0>(G, st);

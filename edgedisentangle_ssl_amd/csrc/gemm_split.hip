@@ -841,10 +841,12 @@ __global__ __launch_bounds__(256) void wamax_kernel(const float* __restrict__ W,
 }
 
 // One element of the split: position i of the [batch][N][K] output order (coalesced plane writes), scale s.
+// I: the integer type of the index arithmetic (the one-launch form of small weights divides in 32 bits).
+template <typename I>
 __device__ __forceinline__ void wsplit_one(const float* __restrict__ W, int64_t sb, int64_t sk, int64_t sn, int K, int N,
-                                           int64_t kn, int64_t i, float s, uint16_t* __restrict__ planes, int frag) {
-  const int64_t b = i / kn, r = i - b * kn;
-  const int64_t n = r / K, k = r - n * K;
+                                           I kn, I i, float s, uint16_t* __restrict__ planes, int frag) {
+  const I b = i / kn, r = i - b * kn;
+  const I n = r / (I)K, k = r - n * (I)K;
   const float t = W[b * sb + k * sk + n * sn] * s;
   const _Float16 h = (_Float16)t;
   const _Float16 l = (_Float16)((t - (float)h) * 2048.f);
@@ -873,7 +875,7 @@ __global__ __launch_bounds__(256) void wsplit_kernel(const float* __restrict__ W
   if (blockIdx.x == 0 && threadIdx.x == 0) *scale_out = s;
   const int64_t kn = (int64_t)K * N;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256)
-    wsplit_one(W, sb, sk, sn, K, N, kn, i, s, planes, frag);
+    wsplit_one<int64_t>(W, sb, sk, sn, K, N, kn, i, s, planes, frag);
 }
 
 // The same preparation of a SMALL weight (<= WPREP_SMALL elements: the layers of the bundled graphs, whose train_steps
@@ -881,29 +883,70 @@ __global__ __launch_bounds__(256) void wsplit_kernel(const float* __restrict__ W
 // there is no zeroed accumulator, no atomic and no second kernel; then it splits its own share.  Same max, same scale,
 // same planes as the two-launch form, bit for bit.
 constexpr int64_t WPREP_SMALL = 131072;
-__global__ __launch_bounds__(256) void wprep_small_kernel(const float* __restrict__ W, int64_t sb, int64_t sk, int64_t sn, int K,
-                                                          int N, int64_t total, float* __restrict__ amax_scale,
-                                                          uint16_t* __restrict__ planes, int frag) {
-  __shared__ uint32_t wave_max[4];
+constexpr int WPREP_THREADS = 1024, WPREP_PER_BLOCK = 4096;
+__global__ __launch_bounds__(WPREP_THREADS) void wprep_small_kernel(const float* __restrict__ W, int64_t sb, int64_t sk, int64_t sn,
+                                                                    int K, int N, int total, int dense, float* __restrict__ amax_scale,
+                                                                    uint16_t* __restrict__ planes, int frag) {
+  __shared__ uint32_t wave_max[WPREP_THREADS / 64];
   uint32_t m = 0u;
-  const int64_t kn = (int64_t)K * N;
-  for (int64_t i = threadIdx.x; i < total; i += 256) {
-    const int64_t b = i / kn, r = i - b * kn;
-    const int64_t k = r / N, n = r - k * N;
-    m = max(m, __float_as_uint(fabsf(W[b * sb + k * sk + n * sn])));
+  const int kn = K * N;
+  auto upd = [&](float v) { m = max(m, __float_as_uint(fabsf(v))); };
+  if (dense > 0 && (dense & 3) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0) {
+    // the view covers `dense` consecutive floats from W (any order of its dimensions; broadcast dimensions counted once):
+    // the maximum does not care about the order.  8 independent 16-byte loads per thread and batch - the loop is latency,
+    // not bandwidth (one batch covers 32 768 floats)
+    const int n4 = dense >> 2;
+    for (int base = threadIdx.x; base < n4; base += 8 * WPREP_THREADS) {
+      f32x4 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int idx = base + j * WPREP_THREADS;
+        v[j] = idx < n4 ? ld4(W + (int64_t)idx * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { upd(v[j].x); upd(v[j].y); upd(v[j].z); upd(v[j].w); }
+    }
+  } else if (dense > 0) {
+    for (int base = threadIdx.x; base < dense; base += 8 * WPREP_THREADS) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int idx = base + j * WPREP_THREADS;
+        v[j] = idx < dense ? W[idx] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) upd(v[j]);
+    }
+  } else {
+    const int scan = sb == 0 ? kn : total;          // a weight broadcast over the batch (one MLP for every head): one copy
+    for (int base = threadIdx.x; base < scan; base += 4 * WPREP_THREADS) {
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int i = base + j * WPREP_THREADS;
+        const int bb = i / kn, r = i - bb * kn;
+        const int k = r / N, n = r - k * N;
+        v[j] = i < scan ? W[bb * sb + k * sk + n * sn] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) upd(v[j]);
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
   if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = m;
   __syncthreads();
-  m = max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3]));
+  m = 0u;
+#pragma unroll
+  for (int w = 0; w < WPREP_THREADS / 64; ++w) m = max(m, wave_max[w]);
   const float s = f16_scale(__uint_as_float(m));
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     amax_scale[0] = __uint_as_float(m);
     amax_scale[1] = s;
   }
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256)
-    wsplit_one(W, sb, sk, sn, K, N, kn, i, s, planes, frag);
+  const int lo = blockIdx.x * WPREP_PER_BLOCK, hi = min(total, lo + WPREP_PER_BLOCK);
+#pragma unroll 4
+  for (int i = lo + threadIdx.x; i < hi; i += WPREP_THREADS) wsplit_one<int>(W, sb, sk, sn, K, N, kn, i, s, planes, frag);
 }
 
 // max |A| over a (batched, strided) fp32 operand into *out (a device float the caller zeroed): the bit pattern
@@ -937,6 +980,7 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ A, 
 }  // namespace disgat
 
 // ------------------------------------------------------------------------------------------
+#include <utility>
 #include "disgat_api.h"
 
 namespace disgat {
@@ -1007,8 +1051,21 @@ static int split_f16_impl(const float* W, int64_t stride_b, int64_t stride_k, in
                           uint16_t* planes, float* amax_scale, int frag, hipStream_t st) {
   if ((int64_t)batch * K * N <= WPREP_SMALL) {
     const int64_t tot = (int64_t)batch * K * N;
-    hipLaunchKernelGGL(wprep_small_kernel, dim3((unsigned)(tot / 4096 + 1)), dim3(256), 0, st, W, stride_b, stride_k, stride_n,
-                       K, N, tot, amax_scale, planes, frag);
+    // does the view cover one run of consecutive floats starting at W?  (dimensions in stride order, each stride = the
+    // extent below it; a broadcast dimension - stride 0 - or one of size 1 adds nothing)
+    int64_t dims[3][2] = {{stride_b, batch}, {stride_k, K}, {stride_n, N}};
+    for (int i = 0; i < 3; ++i)
+      for (int j = i + 1; j < 3; ++j)
+        if (dims[j][0] < dims[i][0]) { std::swap(dims[i][0], dims[j][0]); std::swap(dims[i][1], dims[j][1]); }
+    int64_t extent = 1;
+    bool dense = true;
+    for (int i = 0; i < 3; ++i) {
+      if (dims[i][1] == 1 || dims[i][0] == 0) continue;
+      if (dims[i][0] != extent) { dense = false; break; }
+      extent *= dims[i][1];
+    }
+    hipLaunchKernelGGL(wprep_small_kernel, dim3((unsigned)((tot + WPREP_PER_BLOCK - 1) / WPREP_PER_BLOCK)), dim3(WPREP_THREADS), 0, st,
+                       W, stride_b, stride_k, stride_n, K, N, (int)tot, dense ? (int)extent : 0, amax_scale, planes, frag);
     return check_launch("wprep_small_kernel");
   }
   const hipError_t e = hipMemsetAsync(amax_scale, 0, 2 * sizeof(float), st);

@@ -293,6 +293,8 @@ def _wgrad_blas(a, g):
     batched = a.dim() == 3
     hb = a.shape[0] if batched else 1
     s = min(64, m // 256, max(1, 512 // max(1, hb * -(-k // 64) * -(-n // 64))))
+    if m < 8192:
+        s = 1         # Cora / chameleon-sized: the one GEMM takes ~10 us, the cut form four launches of a launch-bound step
     if s < 2 or not a.is_cuda:
         return torch.bmm(a.transpose(1, 2), g) if batched else a.t() @ g
     rows = m // s

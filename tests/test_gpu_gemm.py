@@ -239,7 +239,10 @@ def test_skinny_linear_matches_fp64(m, k, n, bias):
     assert not ops_gemm.skinny_ok(x[:, :128], lin) and not ops_gemm.skinny_ok(x.cpu(), lin)
 
 
-@pytest.mark.parametrize("m,hb,k,n,act", [(2708, 8, 64, 64, 1), (19793, 8, 64, 64, 1), (1000, 4, 128, 32, 2), (513, 2, 256, 96, 0)])
+@pytest.mark.parametrize("m,hb,k,n,act", [(2708, 8, 64, 64, 1), (19793, 8, 64, 64, 1), (1000, 4, 128, 32, 2), (513, 2, 256, 96, 0),
+                                          # few row blocks: the launcher shares a row block's column chunks among 2-16 workgroups
+                                          (2277, 1, 64, 1024, 0), (2708, 1, 64, 1024, 2), (700, 2, 128, 512, 1), (5000, 1, 256, 384, 0),
+                                          (40000, 1, 64, 256, 1), (1, 1, 64, 128, 0)])
 def test_narrow_outputs_run_on_the_library_kernel(m, hb, k, n, act, monkeypatch):
     """N % 32 (not 128) for K = 64 / 128 / 256: the register-stationary kernel (csrc/gemm_rs.hip) takes the nhid = 64 layers
     of the bundled graphs (per-head projection [64 -> 64] x 8 heads, batched, with bias / additive input / activation) that

@@ -87,6 +87,21 @@ for n, (tr, a) in kept.items():
                 p = p.cpu_parent
             kn = ",".join(k.name.split("(")[0].split("::")[-1][:28] for k in ev.kernels)
             print(f"   {len(ev.kernels):2d} {ev.name.replace('aten::', ''):28s} <- {' <- '.join(chain[:4]):60s} [{kn}]")
+    if os.environ.get("OP_SITES_KERNELS") == "1":   # every device launch in time order, with the CPU op that made it (if any)
+        owner = {}
+        for ev in prof.events():
+            if ev.device_type != torch.autograd.DeviceType.CUDA and ev.kernels and not any(c.kernels for c in ev.cpu_children):
+                chain, p = [ev.name.replace("aten::", "")], ev.cpu_parent
+                while p is not None and len(chain) < 3:
+                    chain.append(p.name.replace("aten::", "").replace("autograd::engine::evaluate_function: ", ""))
+                    p = p.cpu_parent
+                for k in ev.kernels:
+                    owner[(k.name, k.time_range.start if hasattr(k, "time_range") else 0)] = " <- ".join(chain)
+        devs = sorted((e for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA), key=lambda e: e.time_range.start)
+        print(f"\n== {n}: {len(devs)} device launches in order")
+        for e in devs:
+            nm = e.name.split("(")[0].replace("void ", "").replace("at::native::", "").replace("disgat::", "D:")[:70]
+            print(f"   {nm:70s} {e.time_range.elapsed_us():7.1f} us")
     print(f"\n== {n}: {n_launch} launches attributed")
     for s, c in by_site.most_common(int(os.environ.get("OP_SITES_TOP", 60))):
         ops = ", ".join(f"{o.replace('aten::', '')} x{k}" for o, k in by_site_ops[s].most_common(6))
