@@ -568,7 +568,17 @@ __global__ __launch_bounds__(256) void seg_combine_kernel(const int32_t* __restr
   uint32_t mx = 0u;
   for (int c = threadIdx.x * 4; c < width; c += 256 * 4) {
     f32x4 acc = accumulate ? ld4(out + c) : f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int sl = s0; sl < s1; ++sl) acc += ld4(part + (size_t)sl * ld + c);
+    // eight records in flight, added in slice order (a hub of a small graph has tens of slices: one load at a time the
+    // loop was a chain of memory round trips - 13 us per launch on chameleon)
+    int sl = s0;
+    for (; sl + 8 <= s1; sl += 8) {
+      f32x4 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = ld4(part + (size_t)(sl + j) * ld + c);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc += v[j];
+    }
+    for (; sl < s1; ++sl) acc += ld4(part + (size_t)sl * ld + c);
     st4(out + c, acc);
     mx = amax4(mx, acc);
   }
