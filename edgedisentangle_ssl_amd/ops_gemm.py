@@ -284,6 +284,28 @@ def _weight_grad(a, g, a_amax, g_amax):
     return out if batched else out[0]
 
 
+def _wgrad_small_ok(a, g, m, k, n, hb):
+    """Shapes disgat_wgrad_small is for: a result of at most 256 K floats (a few 64 x 64 tiles: the nhid = 64 layers) reduced
+    over at least 512 rows; fp32, unit inner strides, everything 16-byte aligned.  DISGAT_WGRAD_SMALL=0 switches it off."""
+    if os.environ.get("DISGAT_WGRAD_SMALL", "1") == "0" or mode() == "blas":
+        return False
+    ok = (a.is_cuda and a.dtype == torch.float32 and g.dtype == torch.float32 and m >= 512 and hb * k * n <= 262144
+          and k % 4 == 0 and n % 4 == 0 and a.stride(-1) == 1 and g.stride(-1) == 1 and a.stride(-2) % 4 == 0 and g.stride(-2) % 4 == 0
+          and a.data_ptr() % 16 == 0 and g.data_ptr() % 16 == 0)
+    return ok and (a.dim() == 2 or (a.stride(0) % 4 == 0 and g.stride(0) % 4 == 0))
+
+
+def _wgrad_small(a, g, m, k, n, hb):
+    batched = a.dim() == 3
+    tiles = hb * -(-k // 64) * -(-n // 64)
+    splits = max(1, min(1024, 512 // tiles, m // 32))
+    out = torch.empty((hb, k, n), dtype=torch.float32, device=a.device)
+    part = torch.empty((hb, splits, k, n), dtype=torch.float32, device=a.device) if splits > 1 else None
+    _lib.call("disgat_wgrad_small", a.data_ptr(), a.stride(-2), a.stride(0) if batched else 0, g.data_ptr(), g.stride(-2),
+              g.stride(0) if batched else 0, m, k, n, hb, splits, ops._ptr(part), out.data_ptr(), ops._stream())
+    return out if batched else out[0]
+
+
 def _wgrad_blas(a, g):
     """a^T @ g (2-D, or head-batched [H, M, K] / [H, M, N] views) for the shapes outside the split-K kernel's tiling - the
     nhid = 64 layers of the bundled graphs.  The reduction runs over the M node rows while the result is a few 16 x 16 tiles:
@@ -292,6 +314,8 @@ def _wgrad_blas(a, g):
     m, k, n = a.shape[-2], a.shape[-1], g.shape[-1]
     batched = a.dim() == 3
     hb = a.shape[0] if batched else 1
+    if _wgrad_small_ok(a, g, m, k, n, hb):
+        return _wgrad_small(a, g, m, k, n, hb)
     s = min(64, m // 256, max(1, 512 // max(1, hb * -(-k // 64) * -(-n // 64))))
     if m < 8192:
         s = 1         # Cora / chameleon-sized: the one GEMM takes ~10 us, the cut form four launches of a launch-bound step

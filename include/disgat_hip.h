@@ -79,7 +79,7 @@ extern "C" {
 
 typedef void* disgat_stream_t; /* hipStream_t */
 
-int disgat_abi_version(void);          /* 5 in this revision; changes with any launcher's argument list */
+int disgat_abi_version(void);          /* 6 in this revision; changes with any launcher's argument list */
 const char* disgat_last_error(void);
 
 /* Fused score -> sigmoid -> row softmax -> aggregation for all H heads of one layer.
@@ -268,6 +268,15 @@ int disgat_gemm_f16x3(const float* A, int64_t lda, int64_t a_batch_stride, const
 int disgat_gemm_f16x3_tn(const float* A, int64_t lda, int64_t a_batch_stride, const float* G, int64_t ldg,
                          int64_t g_batch_stride, const float* a_amax, const float* g_amax, float* partials,
                          int M, int Ka, int N, int batch, int splits, disgat_stream_t stream);
+
+/* out[b] = A[b]^T G[b] for a SMALL result (K x N a few 64 x 64 tiles; the nhid = 64 weight gradients of Cora-sized graphs,
+ * where the reduction over the M node rows is long and a library GEMM uses a handful of workgroups): fp32 FMAs, the rows cut
+ * into `splits` ranges (1..1024) whose partial results - partials [batch][splits][K][N], scratch, NULL when splits == 1 - a
+ * second launch adds in range order.  A [M][K] (row stride lda), G [M][N] (ldg); K, N and all strides multiples of 4 floats,
+ * bases 16-byte aligned; out [batch][K][N] contiguous.  Replaces the autograd matmuls behind layers.py:350, 363, 376, 398, 110
+ * and models.py:538 for those shapes. */
+int disgat_wgrad_small(const float* A, int64_t lda, int64_t a_batch_stride, const float* G, int64_t ldg, int64_t g_batch_stride,
+                       int M, int K, int N, int batch, int splits, float* partials, float* out, disgat_stream_t stream);
 
 /* *out = max |A[b][m][k]| over batch x M x K (K, lda, batch stride multiples of 4); 0 for an empty operand. */
 int disgat_amax(const float* A, int64_t lda, int64_t a_batch_stride, int M, int K, int batch, float* out,

@@ -269,3 +269,36 @@ def test_narrow_outputs_run_on_the_library_kernel(m, hb, k, n, act, monkeypatch)
     pre = torch.bmm(ad, wd).permute(1, 0, 2).reshape(m, hb * n) + b.double() + ini.double()
     {0: lambda t: t, 1: torch.nn.functional.elu, 2: lambda t: torch.nn.functional.leaky_relu(t, 0.01)}[act](pre).backward(go.double())
     assert _err(a.grad, ad.grad) < 2e-6 and _err(w.grad, wd.grad) < 2e-5
+
+
+@pytest.mark.parametrize("m,hb,k,n", [(2708, 1, 64, 512), (2277, 8, 64, 64), (19793, 1, 64, 512), (19793, 8, 64, 64), (600, 1, 128, 96),
+                                      (513, 1, 4, 4), (70001, 2, 36, 260), (512, 1, 256, 1024)])
+def test_small_result_weight_gradients(m, hb, k, n, monkeypatch):
+    """disgat_wgrad_small (csrc/wgrad_small.hip): a^T g with a few output tiles and a long row reduction - the nhid = 64 weight
+    gradients of the bundled graphs - against float64, hipBLASLt's fp32 as yardstick; ragged tiles (K, N not multiples of 64),
+    ragged row ranges, head-batched strided views; deterministic; and _wgrad_blas really dispatches to it."""
+    from edgedisentangle_ssl_amd import _lib, ops_gemm
+    gen = torch.Generator(device="cuda").manual_seed(m + k + n)
+    if hb > 1:
+        a = (torch.randn(m, hb, k, device="cuda", generator=gen) * 2.0).permute(1, 0, 2)        # [H, M, K] view of [M, H, K]
+        g = (torch.randn(m, hb, n, device="cuda", generator=gen) * 0.3).permute(1, 0, 2)
+        ref = torch.bmm(a.double().transpose(1, 2), g.double())
+        blas = torch.bmm(a.transpose(1, 2), g)
+    else:
+        a = torch.randn(m, k, device="cuda", generator=gen) * 2.0
+        g = torch.randn(m, n, device="cuda", generator=gen) * 0.3
+        ref = a.double().t() @ g.double()
+        blas = a.t() @ g
+    calls = []
+    real = _lib.call
+    monkeypatch.setattr(_lib, "call", lambda name, *args: (calls.append(name), real(name, *args))[1])
+    got = ops_gemm._wgrad_blas(a, g)
+    assert calls == ["disgat_wgrad_small"]
+    assert got.shape == ref.shape
+    e_got, e_blas = _err(got, ref), _err(blas, ref)
+    assert e_got <= max(2.0 * e_blas, 3e-7), (e_got, e_blas)
+    assert torch.equal(got, ops_gemm._wgrad_blas(a, g))
+    monkeypatch.setenv("DISGAT_WGRAD_SMALL", "0")
+    calls.clear()
+    other = ops_gemm._wgrad_blas(a, g)
+    assert "disgat_wgrad_small" not in calls and _err(other, ref) < 1e-5
