@@ -343,19 +343,22 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void seg_grad_sign_kernel(const Si
     for (int mbase = mb; mbase < me; mbase += 64) {
       const int cnt = min(64, me - mbase);
       const int pv = (lane < cnt) ? (A.perm ? A.perm[mbase + lane] : mbase + lane) : 0;
-      // groups of 4 positions, the next group's loads in flight while the current one is accumulated (2-deep);
-      // lanes >= cnt hold position 0 (valid memory), their gradient is masked
-      auto fetch = [&](uint32_t(&w)[4], float(&gv)[4], int i) {
+      // groups of GS positions, the next group's loads in flight while the current one is accumulated (2-deep);
+      // lanes >= cnt hold position 0 (valid memory), their gradient is masked.  Narrow heads (QN <= 2: the nhid = 64 layers
+      // of the bundled graphs, whose 32-entry items are nothing but a chain of memory round trips) have the registers for
+      // groups of 8 - 16 positions in flight; the wide heads of the large workloads stay at 4
+      constexpr int GS = QN <= 2 ? 8 : 4;
+      auto fetch = [&](uint32_t(&w)[GS], float(&gv)[GS], int i) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < GS; ++t) {
           const int64_t pos = __builtin_amdgcn_readlane(pv, (i + t) & 63);
           w[t] = sg[pos * 64];
           gv[t] = (active && i + t < cnt) ? gh[pos * A.g_pstride] : 0.f;
         }
       };
-      auto accum = [&](const uint32_t(&w)[4], const float(&gv)[4]) {
+      auto accum = [&](const uint32_t(&w)[GS], const float(&gv)[GS]) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < GS; ++t) {
           __builtin_amdgcn_sched_barrier(0);      // one position at a time: keeps the 32 bit->float temporaries from piling up
           gall += gv[t];
 #pragma unroll
@@ -367,14 +370,14 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void seg_grad_sign_kernel(const Si
           }
         }
       };
-      uint32_t wA[4], wB[4];
-      float gA[4], gB[4];
+      uint32_t wA[GS], wB[GS];
+      float gA[GS], gB[GS];
       fetch(wA, gA, 0);
-      for (int i = 0; i < cnt; i += 8) {
-        if (i + 4 < cnt) fetch(wB, gB, i + 4);
+      for (int i = 0; i < cnt; i += 2 * GS) {
+        if (i + GS < cnt) fetch(wB, gB, i + GS);
         accum(wA, gA);
-        if (i + 8 < cnt) fetch(wA, gA, i + 8);
-        if (i + 4 < cnt) accum(wB, gB);
+        if (i + 2 * GS < cnt) fetch(wA, gA, i + 2 * GS);
+        if (i + GS < cnt) accum(wB, gB);
       }
     }
     float* op = seg_out_row(A.gkey, A.part, A.ld_gkey, key, slot) + qoff;
