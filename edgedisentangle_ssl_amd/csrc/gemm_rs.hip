@@ -357,11 +357,11 @@ bool gemm_rs_takes(int N, int K) { return (K == 64 || K == 128 || K == 256) && N
 int launch_gemm_f16x3_rs(const GemmHArgs& G0, hipStream_t st) {
   GemmHArgs G = G0;
   G.nt = (RS_DIAG && getenv("DISGAT_RS_DEBUG")) ? atoi(getenv("DISGAT_RS_DEBUG")) : 0;     // (nt is unused by this kernel)
-  // column splits (G.mt, see the kernel): double while the grid stays within the chip's 256 CUs x 2 resident blocks and a
+  // column splits (G.mt, see the kernel): double while the grid stays within two rounds of the chip's 256 CUs x 2 resident blocks and a
   // block keeps at least 2 chunks (the ring's prologue requests 3)
   const int64_t row_blocks = (int64_t)((G.M + RS_BM - 1) / RS_BM) * G.batch;
   int ns = 1;
-  for (int n_ch = G.N / RS_CH; n_ch % 2 == 0 && n_ch >= 4 && row_blocks * ns * 2 <= 512; n_ch /= 2) ns *= 2;
+  for (int n_ch = G.N / RS_CH; n_ch % 2 == 0 && n_ch >= 4 && row_blocks * ns * 2 <= 1024; n_ch /= 2) ns *= 2;
   G.mt = ns;
   if (G.act == 1) return launch_rs_kt<1>(G, st);
   if (G.act == 2) return launch_rs_kt<2>(G, st);

@@ -12,6 +12,7 @@
 
 namespace {
 using namespace disgat;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int WG_T = 64;      // output tile edge
 constexpr int WG_R = 16;      // rows per LDS step
@@ -39,11 +40,11 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(const WgArgs A) {
   const int lr = tid >> 4, lc = (tid & 15) * 4;
   const bool a_ok = k0 + lc < A.K, g_ok = n0 + lc < A.N;       // K, N are multiples of 4: a float4 is inside or outside
   const int ty = tid >> 4, tx = tid & 15;                       // compute role: k = k0 + 4 ty .. +3, n = n0 + 4 tx .. +3
-  float acc[4][4];
+  f32x2 acc[4][2];              // pairs of neighbouring n: one v_pk_fma_f32 per pair (the plain form ran at half the FMA rate)
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x2{0.f, 0.f};
   const f32x4 zero{0.f, 0.f, 0.f, 0.f};
   auto fetch = [&](int m, f32x4& va, f32x4& vg) {
     const bool in = m + lr < m_hi;
@@ -62,11 +63,13 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(const WgArgs A) {
     for (int r = 0; r < WG_R; ++r) {
       const f32x4 x = *reinterpret_cast<const f32x4*>(&As[buf][r][ty * 4]);
       const f32x4 y = *reinterpret_cast<const f32x4*>(&Gs[buf][r][tx * 4]);
-      const float xs[4] = {x.x, x.y, x.z, x.w}, ys[4] = {y.x, y.y, y.z, y.w};
+      const float xs[4] = {x.x, x.y, x.z, x.w};
+      const f32x2 y01{y.x, y.y}, y23{y.z, y.w};
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(xs[i], ys[j], acc[i][j]);
+      for (int i = 0; i < 4; ++i) {
+        acc[i][0] += f32x2{xs[i], xs[i]} * y01;
+        acc[i][1] += f32x2{xs[i], xs[i]} * y23;
+      }
     }
   }
   float* out = A.out + (((int64_t)bz * A.splits + sp) * A.K) * A.N;
@@ -74,7 +77,7 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(const WgArgs A) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int k = k0 + ty * 4 + i;
-      if (k < A.K) st4(out + (int64_t)k * A.N + n0 + tx * 4, f32x4{acc[i][0], acc[i][1], acc[i][2], acc[i][3]});
+      if (k < A.K) st4(out + (int64_t)k * A.N + n0 + tx * 4, f32x4{acc[i][0].x, acc[i][0].y, acc[i][1].x, acc[i][1].y});
     }
   }
 }
