@@ -23,7 +23,8 @@ def _case(n, c, seed, frac=(0.3, 0.2), pad=0):
     return logits, labels, idx_tr, idx_va, code
 
 
-@pytest.mark.parametrize("n,c,pad", [(2277, 5, 0), (2708, 7, 1), (1, 3, 0), (8192, 70, 0), (8193, 4, 0), (300_000, 10, 2)])
+@pytest.mark.parametrize("n,c,pad", [(2277, 5, 0), (2708, 7, 1), (1, 3, 0), (8192, 70, 0), (8193, 4, 0), (300_000, 10, 2),
+                                     (5000, 16, 0), (3000, 8, 4), (20_000, 8, 0), (777, 4, 1)])
 def test_matches_log_softmax_nll_accuracy(n, c, pad):
     from edgedisentangle_ssl_amd import ops
     logits, labels, idx_tr, idx_va, code = _case(n, c, 100 + n % 97, pad=pad)
