@@ -274,21 +274,48 @@ __global__ __launch_bounds__(256) void pair_loss_kernel(const float* __restrict_
 
 // acc[q] += sum over blocks of part[b][q] in a FIXED order (lane l adds blocks l, l+64, ... in sequence, then a fixed
 // shuffle tree): deterministic, no floating-point atomics anywhere in the loss.  One wave per quantity.
-__global__ __launch_bounds__(192) void pair_loss_finish_kernel(const double* __restrict__ part, int n_blocks, double* __restrict__ acc) {
+// value (optional) = {loss, neg_w, m}: utils.adj_mse_loss on the whole list (utils.py:287-298: positives weigh 1, zeros
+// n_pos / (m^2 - n_pos), mean over the m valid pairs) - the scalar arithmetic the host formulation spent ~10 launches on.
+__global__ __launch_bounds__(192) void pair_loss_finish_kernel(const double* __restrict__ part, int n_blocks, double* __restrict__ acc,
+                                                               const double* __restrict__ count, double m_host,
+                                                               double* __restrict__ value, float* __restrict__ loss32) {
+  __shared__ double tot[3];
   const int q = threadIdx.x >> 6, lane = threadIdx.x & 63;
   double t = 0.0;
   for (int b = lane; b < n_blocks; b += 64) t += part[(size_t)b * 3 + q];
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
-  if (lane == 0) acc[q] += t;
+  if (lane == 0) {
+    acc[q] = t;
+    tot[q] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && value != nullptr) {
+    const double m = count != nullptr ? *count : m_host;
+    const double neg_w = tot[2] / (m * m - tot[2]);
+    const double loss = (tot[0] + neg_w * tot[1]) / m;
+    value[0] = loss;
+    value[1] = neg_w;
+    value[2] = m;
+    if (loss32 != nullptr) *loss32 = (float)loss;
+  }
 }
 
 // Backward of the same loss: d loss / d aux[h][m] = coef[t_m != 0 ? 0 : 1] * 2 (p - t) p (1 - p) for h in [h_lo, h_hi), 0 for
 // the other rows (coef = upstream gradient x class weight / M, prepared by the host on the device).
 __global__ __launch_bounds__(256) void pair_loss_bwd_kernel(const float* __restrict__ aux, int64_t M, int H, int h_lo, int h_hi,
                                                             const float* __restrict__ labels, const float* __restrict__ coef,
+                                                            const double* __restrict__ value, const float* __restrict__ gout,
                                                             float* __restrict__ g, int transposed) {
-  const float c_pos = coef[0], c_neg = coef[1];
+  float c_pos, c_neg;
+  if (coef != nullptr) {
+    c_pos = coef[0];
+    c_neg = coef[1];
+  } else {                       // from the forward's {loss, neg_w, m} and the upstream gradient
+    const double per = (double)gout[0] / value[2];
+    c_pos = (float)per;
+    c_neg = (float)(value[1] * per);
+  }
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += stride) {
     float s = 0.f;
@@ -409,27 +436,31 @@ extern "C" int disgat_aux_score(int att, const int64_t* pair_rows, const int64_t
   }
 }
 
-extern "C" int disgat_pair_loss(const float* aux, int64_t M, int h_lo, int h_hi, const float* labels, double* acc,
-                                double* block_partials, disgat_stream_t stream) {
+extern "C" int disgat_pair_loss(const float* aux, int64_t M, int h_lo, int h_hi, const float* labels, const double* count,
+                                double* acc, double* block_partials, double* value, float* loss32, disgat_stream_t stream) {
   using namespace disgat;
-  DISGAT_REQUIRE(aux && labels && acc && block_partials && M >= 0 && h_lo >= 0 && h_hi >= h_lo, "pair_loss: bad arguments");
-  if (M == 0) return 0;
+  DISGAT_REQUIRE(acc && block_partials && M >= 0 && h_lo >= 0 && h_hi >= h_lo, "pair_loss: bad arguments");
+  DISGAT_REQUIRE(M == 0 || (aux && labels), "pair_loss: null scores / labels");
+  DISGAT_REQUIRE(loss32 == nullptr || value != nullptr, "pair_loss: loss32 needs value");
   const int grid = (int)min((int64_t)DISGAT_PAIR_LOSS_MAX_BLOCKS, (M + 255) / 256);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(pair_loss_kernel, dim3(grid), dim3(256), 0, st, aux, M, h_lo, h_hi, labels, block_partials);
-  if (int rc = check_launch("pair_loss_kernel")) return rc;
-  hipLaunchKernelGGL(pair_loss_finish_kernel, dim3(1), dim3(192), 0, st, block_partials, grid, acc);
+  if (grid > 0) {
+    hipLaunchKernelGGL(pair_loss_kernel, dim3(grid), dim3(256), 0, st, aux, M, h_lo, h_hi, labels, block_partials);
+    if (int rc = check_launch("pair_loss_kernel")) return rc;
+  }
+  hipLaunchKernelGGL(pair_loss_finish_kernel, dim3(1), dim3(192), 0, st, block_partials, grid, acc, count, (double)M, value, loss32);
   return check_launch("pair_loss_finish_kernel");
 }
 
 extern "C" int disgat_pair_loss_bwd(const float* aux, int64_t M, int H, int h_lo, int h_hi, const float* labels,
-                                    const float* coef, float* g, int g_transposed, disgat_stream_t stream) {
+                                    const float* coef, const double* value, const float* gout, float* g, int g_transposed,
+                                    disgat_stream_t stream) {
   using namespace disgat;
-  DISGAT_REQUIRE(aux && labels && coef && g && M >= 0 && H > 0 && h_lo >= 0 && h_hi >= h_lo && h_hi <= H,
-                 "pair_loss_bwd: bad arguments");
+  DISGAT_REQUIRE(aux && labels && g && M >= 0 && H > 0 && h_lo >= 0 && h_hi >= h_lo && h_hi <= H, "pair_loss_bwd: bad arguments");
+  DISGAT_REQUIRE(coef != nullptr || (value != nullptr && gout != nullptr), "pair_loss_bwd: either coef or (value, gout)");
   if (M == 0) return 0;
   const int grid = (int)min((int64_t)4096, (M + 255) / 256);
   hipLaunchKernelGGL(pair_loss_bwd_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), aux, M, H, h_lo,
-                     h_hi, labels, coef, g, g_transposed);
+                     h_hi, labels, coef, value, gout, g, g_transposed);
   return check_launch("pair_loss_bwd_kernel");
 }

@@ -208,17 +208,23 @@ def aux_forward(att, H, F_in, F_out, pairs, n, x, rowop, colop, a, h_lo=0, h_hi=
     return out
 
 
-def pair_loss_sums(aux, h_lo, h_hi, labels):
-    """disgat_pair_loss: returns a float64 device tensor [sum_sq_pos, sum_sq_neg, n_pos]."""
+def pair_loss_sums(aux, h_lo, h_hi, labels, count=None, want_value=False):
+    """disgat_pair_loss: a float64 device tensor [sum_sq_pos, sum_sq_neg, n_pos]; with want_value also (loss32, value):
+    the list's utils.adj_mse_loss as a 0-d fp32 tensor and float64 {loss, neg_w, m}, finished inside the same launches
+    (m = `count`, a 0-d float64 device tensor - the valid length of a fixed-capacity list - or the list length)."""
     _check(aux, "aux")
     _check(labels, "labels")
-    acc = torch.zeros(3, dtype=torch.float64, device=aux.device)
     if aux.stride(1) != 1 or aux.stride(0) != aux.shape[1]:
         raise RuntimeError("aux must be a contiguous [H,M] tensor")
+    if count is not None and (count.dtype != torch.float64 or not count.is_cuda or count.numel() != 1):
+        raise RuntimeError("pair_loss: count must be one float64 on the device")
+    acc = torch.empty(3, dtype=torch.float64, device=aux.device)
     part = torch.empty((2048, 3), dtype=torch.float64, device=aux.device)      # DISGAT_PAIR_LOSS_MAX_BLOCKS per-block sums
-    _lib.call("disgat_pair_loss", _ptr(aux), int(aux.shape[1]), h_lo, h_hi, _ptr(labels.contiguous()), _ptr(acc), _ptr(part),
-              _stream())
-    return acc
+    value = torch.empty(3, dtype=torch.float64, device=aux.device) if want_value else None
+    loss32 = torch.empty((), dtype=torch.float32, device=aux.device) if want_value else None
+    _lib.call("disgat_pair_loss", _ptr(aux), int(aux.shape[1]), h_lo, h_hi, _ptr(labels.contiguous()), _ptr(count), _ptr(acc),
+              _ptr(part), _ptr(value), _ptr(loss32), _stream())
+    return (acc, loss32, value) if want_value else acc
 
 
 class ClsLoss(torch.autograd.Function):

@@ -52,41 +52,57 @@ def _graph_sampler(graph):
 
 
 def _pair_loss_value(base, h_lo, h_hi, labels, graph):
-    """(loss, neg_w, m) from the HIP partial sums; on a sharded graph sums and pair count are all-reduced (global loss)."""
-    acc = ops.pair_loss_sums(base, h_lo, h_hi, labels)
+    """(loss, neg_w, m, value) of utils.adj_mse_loss on the list.  Unsharded: finished inside the pair-loss launches (value =
+    the kernel's {loss, neg_w, m}); on a sharded graph sums and pair count are all-reduced first (global loss; value None)."""
     count = getattr(labels, "_disgat_count", None)      # fixed-capacity list (sampling.PairSampler.sample_static): its valid length, on the device
+    if not (isinstance(graph, parallel.DistGraph) and graph.world > 1):
+        _acc, loss, value = ops.pair_loss_sums(base, h_lo, h_hi, labels, count=count, want_value=True)
+        return loss, value[1], value[2], value
+    acc = ops.pair_loss_sums(base, h_lo, h_hi, labels)
     if count is None:
         count = acc.new_full((1,), float(labels.shape[0]))                 # fill kernel: stays graph-capturable
     acc = torch.cat([acc, count.reshape(1).to(acc.dtype)])
     parallel.all_reduce_sum(acc, graph)
     m = acc[3]
     neg_w = acc[2] / (m * m - acc[2])
-    return ((acc[0] + neg_w * acc[1]) / m).to(torch.float32), neg_w, m
+    return ((acc[0] + neg_w * acc[1]) / m).to(torch.float32), neg_w, m, None
 
 
 class _PairLoss(torch.autograd.Function):
-    """Differentiable weighted-MSE pair loss on the [H,M] score buffer: forward = the partial-sum kernel, backward =
-    one kernel writing d loss / d score for every row (the torch formulation took ~10 passes over [M] / [H,M]
-    temporaries per loss).  Sharded: the value is the global loss, the gradient this rank's part (global weights)."""
+    """Differentiable weighted-MSE pair loss on the [H,M] score buffer: forward = the partial-sum kernel + its finish (which
+    also does the class-weight / mean arithmetic), backward = one kernel writing d loss / d score for every row (the torch
+    formulation took ~10 passes over [M] / [H,M] temporaries per loss, and the scalar arithmetic around the kernels another
+    15 launches per list).  Sharded: the value is the global loss, the gradient this rank's part (global weights)."""
 
     @staticmethod
     def forward(ctx, base, labels, h_lo, h_hi, graph):
-        loss, neg_w, m = _pair_loss_value(base, h_lo, h_hi, labels, graph)
-        ctx.save_for_backward(base, labels, neg_w, m)
+        loss, neg_w, m, value = _pair_loss_value(base, h_lo, h_hi, labels, graph)
+        ctx.fused = value is not None
+        if ctx.fused:
+            ctx.save_for_backward(base, labels, value)
+        else:
+            ctx.save_for_backward(base, labels, neg_w, m)
         ctx.rng = (h_lo, h_hi)
         return loss
 
     @staticmethod
     def backward(ctx, gout):
-        base, labels, neg_w, m = ctx.saved_tensors
         h_lo, h_hi = ctx.rng
-        coef = (torch.stack([torch.ones_like(neg_w), neg_w]) * (gout.double() / m)).to(torch.float32).contiguous()
+        from . import _lib
+        if ctx.fused:
+            base, labels, value = ctx.saved_tensors
+            coef = None
+            gout = gout.reshape(1).to(torch.float32).contiguous()
+        else:
+            base, labels, neg_w, m = ctx.saved_tensors
+            value = None
+            coef = (torch.stack([torch.ones_like(neg_w), neg_w]) * (gout.double() / m)).to(torch.float32).contiguous()
         # [H, M] gradient backed by an [M, H] buffer: the segment passes of the score backward (ops_bwd._g_strides) then find
         # a pair's H values in one 32-byte run - the column-side pass visits the pairs in column order, i.e. at random
         g = torch.empty((base.shape[1], base.shape[0]), dtype=base.dtype, device=base.device)
-        from . import _lib
         _lib.call("disgat_pair_loss_bwd", base.data_ptr(), int(base.shape[1]), int(base.shape[0]), h_lo, h_hi,
-                  labels.data_ptr(), coef.data_ptr(), g.data_ptr(), 1, ops._stream())
+                  labels.data_ptr(), ops._ptr(coef), ops._ptr(value), ops._ptr(None if coef is not None else gout), g.data_ptr(), 1,
+                  ops._stream())
         return g.t(), None, None, None, None
 
 

@@ -79,7 +79,7 @@ extern "C" {
 
 typedef void* disgat_stream_t; /* hipStream_t */
 
-int disgat_abi_version(void);          /* 6 in this revision; changes with any launcher's argument list */
+int disgat_abi_version(void);          /* 7 in this revision; changes with any launcher's argument list */
 const char* disgat_last_error(void);
 
 /* Fused score -> sigmoid -> row softmax -> aggregation for all H heads of one layer.
@@ -115,15 +115,19 @@ int disgat_aux_score(int att, const int64_t* pair_rows, const int64_t* pair_cols
                      const float* a,
                      float* out, uint32_t* sign_bits, disgat_stream_t stream);
 
-/* Weighted squared-error partial sums of pred = sigmoid(sum_{h in [h_lo,h_hi)} aux[h][m])
- * against 0/1 labels: acc[0] += sum over positives, acc[1] += sum over zeros, acc[2] += #positives.
+/* Weighted squared-error sums of pred = sigmoid(sum_{h in [h_lo,h_hi)} aux[h][m]) against 0/1 labels:
+ * acc[0] = sum over positives, acc[1] = sum over zeros, acc[2] = #positives (3 doubles, WRITTEN - no zeroing needed).
  * A NEGATIVE label marks padding (a fixed-capacity list whose valid length lives on the device, as a step captured
  * in a HIP graph needs): such an entry enters no sum and gets a zero gradient from disgat_pair_loss_bwd.
- * acc (3 doubles) must be zeroed by the caller; block_partials: scratch for DISGAT_PAIR_LOSS_MAX_BLOCKS x 3 doubles
- * (per-block sums, added in block order by a second tiny launch: the value is run-to-run deterministic). */
+ * block_partials: scratch for DISGAT_PAIR_LOSS_MAX_BLOCKS x 3 doubles (per-block sums, added in block order by a second
+ * tiny launch: the value is run-to-run deterministic).
+ * value (optional, 3 doubles) = {loss, neg_w, m}: utils.adj_mse_loss of the whole list (utils.py:287-298) - m = *count (a
+ * device double: the valid length of a fixed-capacity list) or M when count is NULL, neg_w = acc[2] / (m^2 - acc[2]),
+ * loss = (acc[0] + neg_w acc[1]) / m; loss32 (optional, needs value) = (float)loss.  A caller that must combine several
+ * processes' sums first passes value = NULL and finishes on its side. */
 #define DISGAT_PAIR_LOSS_MAX_BLOCKS 2048
-int disgat_pair_loss(const float* aux, int64_t M, int h_lo, int h_hi, const float* labels,
-                     double* acc, double* block_partials, disgat_stream_t stream);
+int disgat_pair_loss(const float* aux, int64_t M, int h_lo, int h_hi, const float* labels, const double* count,
+                     double* acc, double* block_partials, double* value, float* loss32, disgat_stream_t stream);
 
 /* Classification loss in one pass over logits [n_rows][n_cls] (row stride ld): per row log_softmax (written to logp when
  * non-NULL, row stride ld_logp), and over the rows of split s = 0, 1 the sums of -logp[label] and of (argmax == label).
@@ -148,12 +152,13 @@ int disgat_cls_loss(const float* logits, int64_t ld, const int32_t* row_code, in
 int disgat_cls_loss_bwd(const float* logp, int64_t ld_logp, const int32_t* row_code, int label_mod, int64_t n_rows,
                         int n_cls, const float* g, double div0, float* grad_logits, int64_t ld_grad, disgat_stream_t stream);
 
-/* Gradient of that loss w.r.t. the raw scores: g[h][m] = coef[labels[m] != 0 ? 0 : 1] * 2 (p - t) p (1 - p) for h in
- * [h_lo, h_hi), 0 for the other of the H rows; coef = 2 device floats (upstream gradient x class weight / M).
- * g_transposed != 0: g is written as [M][H] (g[m][h]) - the layout in which disgat_seg_grad_sign's column-side pass,
- * which visits the pairs in column order, finds the H gradients of a pair in one 32-byte run instead of H sectors. */
-int disgat_pair_loss_bwd(const float* aux, int64_t M, int H, int h_lo, int h_hi, const float* labels,
-                         const float* coef, float* g, int g_transposed, disgat_stream_t stream);
+/* Gradient of disgat_pair_loss's loss w.r.t. the raw scores: g[h][m] = c[labels[m] != 0 ? 0 : 1] * 2 (p - t) p (1 - p) for h
+ * in [h_lo, h_hi), 0 for the other of the H rows.  c = coef (2 device floats: upstream gradient x class weight / m) or, with
+ * coef == NULL, {gout / m, neg_w gout / m} from the forward's value = {loss, neg_w, m} and the upstream gradient gout (one
+ * device float).  g_transposed != 0: g is written as [M][H] (g[m][h]) - the layout in which disgat_seg_grad_sign's
+ * column-side pass, which visits the pairs in column order, finds the H gradients of a pair in one 32-byte run. */
+int disgat_pair_loss_bwd(const float* aux, int64_t M, int H, int h_lo, int h_hi, const float* labels, const float* coef,
+                         const double* value, const float* gout, float* g, int g_transposed, disgat_stream_t stream);
 
 /* Per edge and head: ge_out = ge_in + d(loss)/d(e) through softmax-of-sigmoid given gZ (grad of Z),
  * and beta = alpha*sc, the coefficient of x[col] in Z (used by the transposed pass for grad x).
