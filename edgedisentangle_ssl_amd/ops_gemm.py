@@ -208,6 +208,8 @@ def _forward(a, w, bias, init, act, slope, a_amax=None, w_split=None, out=None):
             if bias is not None:
                 out3 = out3 + bias.view(hb, 1, n)
             out = out3.permute(1, 0, 2).reshape(m, hb * n)
+        elif bias is not None and bias.dim() == 1:
+            out = torch.addmm(bias, a, w)              # one launch (a @ w, then + bias, were two)
         else:
             out = a @ w
             if bias is not None:
