@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libdisgat_hip.so")
 SOURCES = ["api_common.hip", "edge_fwd.hip", "aux_score.hip", "edge_bwd.hip", "gemm_split.hip", "gemm_rs.hip", "gemm_planes.hip", "linear_skinny.hip",
            "optim.hip", "pair_sample.hip", "seg_tables.hip", "cls_loss.hip", "wgrad_small.hip"]
 ARCH = "gfx950"
-ABI_VERSION = 7         # csrc/api_common.hip: bumped whenever a launcher's argument list changes (round 3: dropout seed
+ABI_VERSION = 8         # csrc/api_common.hip: bumped whenever a launcher's argument list changes (round 3: dropout seed
                         # counter, padding labels / items, score-gradient strides, amax outputs, plane outputs; round 4: pair sampler, classification loss, small weight gradients)
 
 _lib = None
@@ -96,6 +96,7 @@ _SIGS = {
                                     _c.c_int, _P, _c.c_int, _P, _c.c_int, _P, _c.c_int, _P, _P, _P, _P]),
     "disgat_pair_loss": (_c.c_int, [_P, _c.c_int64, _c.c_int, _c.c_int, _P, _P, _P, _P, _P, _P, _P]),
     "disgat_pair_loss_bwd": (_c.c_int, [_P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _P, _P, _P, _P, _P, _c.c_int, _P]),
+    "disgat_weight_bound": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _P, _c.c_float, _c.c_float, _P, _P]),
     "disgat_wgrad_small": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _P, _c.c_int64, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
                                       _c.c_int, _P, _P, _P]),
     "disgat_cls_loss": (_c.c_int, [_P, _c.c_int64, _P, _c.c_int, _c.c_int64, _c.c_int, _c.c_double, _c.c_double, _P, _c.c_int64,

@@ -949,6 +949,44 @@ __global__ __launch_bounds__(WPREP_THREADS) void wprep_small_kernel(const float*
   for (int i = lo + threadIdx.x; i < hi; i += WPREP_THREADS) wsplit_one<int>(W, sb, sk, sn, K, N, kn, i, s, planes, frag);
 }
 
+// Bound on |x W| for the f16x3 scale of a GEMM output: max over (batch, column) of sum_k |W[b][k][n]| - the largest column
+// abs-sum - times the bound on |x| and a safety factor, floored (|elu(v)| <= max(|v|, 1)).  The ATen chain (abs, sum, max, mul,
+// mul, clamp) was six launches per layer of a launch-bound step; here one block: a thread per column, 8 rows in flight.
+// out[0] = the largest column abs-sum; out[1] = max(floor, in_bound * out[0] * scale) (in_bound == NULL: not written).
+constexpr int WBOUND_THREADS = 1024;
+__global__ __launch_bounds__(WBOUND_THREADS) void weight_bound_kernel(const float* __restrict__ W, int64_t sb, int64_t sk, int64_t sn,
+                                                                      int K, int N, int batch, const float* __restrict__ in_bound,
+                                                                      float scale, float floor_, float* __restrict__ out) {
+  __shared__ float wave_max[WBOUND_THREADS / 64];
+  float best = 0.f;
+  const int cols = batch * N;
+  for (int c = threadIdx.x; c < cols; c += WBOUND_THREADS) {
+    const int b = c / N, n = c - b * N;
+    const float* p = W + b * sb + n * sn;
+    float s = 0.f;
+    int k = 0;
+    for (; k + 8 <= K; k += 8) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = p[(int64_t)(k + j) * sk];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += fabsf(v[j]);
+    }
+    for (; k < K; ++k) s += fabsf(p[(int64_t)k * sk]);
+    best = fmaxf(best, s);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) best = fmaxf(best, __shfl_xor(best, o, 64));
+  if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = best;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float m = 0.f;
+    for (int w = 0; w < WBOUND_THREADS / 64; ++w) m = fmaxf(m, wave_max[w]);
+    out[0] = m;
+    if (in_bound != nullptr) out[1] = fmaxf(floor_, in_bound[0] * m * scale);
+  }
+}
+
 // max |A| over a (batched, strided) fp32 operand into *out (a device float the caller zeroed): the bit pattern
 // of a non-negative float orders like an unsigned integer, so the reduction is one atomicMax per wave.
 __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ A, int64_t lda, int64_t a_bs, int64_t rows,
@@ -1079,6 +1117,16 @@ static int split_f16_impl(const float* W, int64_t stride_b, int64_t stride_k, in
   return check_launch("wsplit_kernel");
 }
 }  // namespace disgat
+
+extern "C" int disgat_weight_bound(const float* W, int64_t stride_b, int64_t stride_k, int64_t stride_n, int K, int N, int batch,
+                                   const float* in_bound, float scale, float floor_value, float* out, disgat_stream_t stream) {
+  using namespace disgat;
+  DISGAT_REQUIRE(W && out && K > 0 && N > 0 && batch > 0, "weight_bound: null pointer / bad sizes");
+  DISGAT_REQUIRE((int64_t)batch * K * N <= WPREP_SMALL, "weight_bound: one block serves weights of up to %lld elements", (long long)WPREP_SMALL);
+  hipLaunchKernelGGL(weight_bound_kernel, dim3(1), dim3(WBOUND_THREADS), 0, reinterpret_cast<hipStream_t>(stream), W, stride_b, stride_k,
+                     stride_n, K, N, batch, in_bound, scale, floor_value, out);
+  return check_launch("weight_bound_kernel");
+}
 
 extern "C" int disgat_split_f16(const float* W, int64_t stride_b, int64_t stride_k, int64_t stride_n, int K, int N, int batch,
                                 uint16_t* planes, float* amax_scale, disgat_stream_t stream) {

@@ -565,16 +565,20 @@ def _disga_heads(layers, x, adj, aux_indices=None, head_ranges=None, aux_only=Fa
             zt = None
         else:
             zt = z[:, :H, :f_in].permute(1, 0, 2)                           # [H,N,F_in] strided view
+        fused_bound = None
         if use_pl:
             pass
         elif gnn == "AT":                                                    # layers.py:397-399
             def pack_at():
                 w = torch.stack([l.W_em for l in layers])                    # [H,F_in,F_out]
-                return w, ops_gemm.presplit(w), w.detach().abs().sum(1).max()
+                # the largest column abs-sum: small weights get it together with the output bound in one launch below
+                return w, ops_gemm.presplit(w), (w.detach().abs().sum(1).max() if w.numel() > 131072 else None)
 
             w, ws, wnorm = _memo(layers, "proj_AT", pack_at)
             fused = ops_gemm.linear(zt, w, None, None, act_code, a_amax=z_bound, w_split=ws)
-            pre_bound = None if z_bound is None else z_bound * wnorm
+            pre_bound = None if z_bound is None or wnorm is None else z_bound * wnorm
+            if z_bound is not None and wnorm is None:        # |elu(v)| <= max(|v|, 1), v = z W: bound z x column abs-sum
+                fused_bound = ops_gemm.weight_bound(w, z_bound, 1.001, 1.0)[1]
         elif gnn == "SAGE":                                                  # layers.py:96-110
             wx = torch.cat([l.ag_layer.proj.weight[:, :f_in].t() for l in layers], dim=1)   # [F_in, H*F_out]
             wn = torch.stack([l.ag_layer.proj.weight[:, f_in:].t() for l in layers])        # [H,F_in,F_out]
@@ -592,7 +596,8 @@ def _disga_heads(layers, x, adj, aux_indices=None, head_ranges=None, aux_only=Fa
             heads.fused = act
             heads.n_heads, heads.f_out = H, f_out
             # |elu(v)| <= max(|v|, 1)
-            heads.fused_amax = None if pre_bound is None else torch.clamp(pre_bound * 1.001, min=1.0).reshape(1)
+            heads.fused_amax = fused_bound if fused_bound is not None else (
+                None if pre_bound is None else torch.clamp(pre_bound * 1.001, min=1.0).reshape(1))
             heads.pre_elu = None if concat else [fused[:, h * f_out:(h + 1) * f_out] for h in range(H)]
             e_list = [edge_e[h].unsqueeze(1) for h in range(H)]
 

@@ -66,6 +66,21 @@ def split_weight(w):
     return torch.stack([hi, mid, lo], dim=-3).contiguous().view(torch.int16)
 
 
+def weight_bound(w, in_bound=None, scale=1.0, floor=0.0):
+    """(largest column abs-sum of w [K,N] / [H,K,N] as a device scalar, max(floor, in_bound * that * scale) or None): the scale
+    bound of x @ w given a bound on |x| - one launch for small weights (disgat_weight_bound), the ATen chain otherwise."""
+    w = w.detach()
+    w3 = w if w.dim() == 3 else w.unsqueeze(0)
+    if w3.is_cuda and w3.dtype == torch.float32 and w3.numel() <= 131072 and (in_bound is None or in_bound.dtype == torch.float32):
+        out = torch.empty(2, dtype=torch.float32, device=w.device)
+        hb, k, n = w3.shape
+        _lib.call("disgat_weight_bound", w3.data_ptr(), w3.stride(0), w3.stride(1), w3.stride(2), k, n, hb, ops._ptr(in_bound),
+                  float(scale), float(floor), out.data_ptr(), ops._stream())
+        return out[0], (out[1:2] if in_bound is not None else None)
+    norm = w3.abs().sum(1).max()
+    return norm, (None if in_bound is None else torch.clamp(in_bound * norm * scale, min=floor).reshape(1))
+
+
 def _apply_act(t, act, slope):
     if act == ACT_ELU:
         return F.elu(t)

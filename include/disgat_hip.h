@@ -79,7 +79,7 @@ extern "C" {
 
 typedef void* disgat_stream_t; /* hipStream_t */
 
-int disgat_abi_version(void);          /* 7 in this revision; changes with any launcher's argument list */
+int disgat_abi_version(void);          /* 8 in this revision; changes with any launcher's argument list */
 const char* disgat_last_error(void);
 
 /* Fused score -> sigmoid -> row softmax -> aggregation for all H heads of one layer.
@@ -273,6 +273,13 @@ int disgat_gemm_f16x3(const float* A, int64_t lda, int64_t a_batch_stride, const
 int disgat_gemm_f16x3_tn(const float* A, int64_t lda, int64_t a_batch_stride, const float* G, int64_t ldg,
                          int64_t g_batch_stride, const float* a_amax, const float* g_amax, float* partials,
                          int M, int Ka, int N, int batch, int splits, disgat_stream_t stream);
+
+/* Scale bound of a GEMM output x W from a bound on |x|: out[0] = max over (batch, column) of sum_k |W[b][k][n]| (the largest
+ * column abs-sum of an arbitrarily strided [batch][K][N] weight of at most 131 072 elements), and, when in_bound is given,
+ * out[1] = max(floor_value, in_bound[0] * out[0] * scale) - what the host formulation spent six element-wise / reduce launches
+ * per layer on (layers.py has no counterpart: the reference's fp32 GEMMs need no scale). */
+int disgat_weight_bound(const float* W, int64_t stride_b, int64_t stride_k, int64_t stride_n, int K, int N, int batch,
+                        const float* in_bound, float scale, float floor_value, float* out, disgat_stream_t stream);
 
 /* out[b] = A[b]^T G[b] for a SMALL result (K x N a few 64 x 64 tiles; the nhid = 64 weight gradients of Cora-sized graphs,
  * where the reduction over the M node rows is long and a library GEMM uses a handful of workgroups): fp32 FMAs, the rows cut

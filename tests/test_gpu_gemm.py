@@ -302,3 +302,21 @@ def test_small_result_weight_gradients(m, hb, k, n, monkeypatch):
     calls.clear()
     other = ops_gemm._wgrad_blas(a, g)
     assert "disgat_wgrad_small" not in calls and _err(other, ref) < 1e-5
+
+
+def test_weight_bound_matches_the_aten_chain():
+    """disgat_weight_bound: largest column abs-sum of a (batched, strided) weight and max(floor, in_bound * it * scale)."""
+    from edgedisentangle_ssl_amd import ops_gemm
+    g = torch.Generator(device="cuda").manual_seed(3)
+    bound = torch.tensor([2.5], device="cuda")
+    for w in (torch.randn(8, 64, 64, device="cuda", generator=g), torch.randn(300, 70, device="cuda", generator=g).t(),
+              torch.randn(5, 33, 17, device="cuda", generator=g).transpose(1, 2), torch.randn(1, 1, device="cuda", generator=g),
+              torch.randn(600, 400, device="cuda", generator=g)):            # the last one: above the one-block limit (ATen chain)
+        w3 = w if w.dim() == 3 else w.unsqueeze(0)
+        want = w3.double().abs().sum(1).max()
+        norm, out = ops_gemm.weight_bound(w, bound, 1.001, 1.0)
+        assert abs(float(norm) - float(want)) <= 1e-5 * float(want)
+        assert float(out) == pytest.approx(max(1.0, 2.5 * float(norm) * 1.001), rel=1e-6) and out.shape == (1,)
+        assert ops_gemm.weight_bound(w)[1] is None
+    tiny = torch.full((4, 4), 1e-3, device="cuda")
+    assert float(ops_gemm.weight_bound(tiny, bound, 1.001, 1.0)[1]) == 1.0   # the floor
