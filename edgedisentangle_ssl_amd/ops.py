@@ -252,10 +252,13 @@ class ClsLoss(torch.autograd.Function):
         ctx.save_for_backward(logp, code)
         ctx.cfg = (int(label_mod), float(div0))
         ctx.mark_non_differentiable(logp, res)
+        ctx.set_materialize_grads(False)      # no zero tensors for the two outputs nobody differentiates
         return loss, logp, res
 
     @staticmethod
     def backward(ctx, g, _g_logp, _g_res):
+        if g is None:
+            return None, None, None, None, None
         logp, code = ctx.saved_tensors
         label_mod, div0 = ctx.cfg
         n, c = logp.shape
