@@ -114,3 +114,28 @@ def test_fullsize_sign_backward_equals_gather_backward(name, n, e, f):
     for name_, gs, gg in zip(("gP", "gQ", "ga"), grads[True], grads[False]):
         scale = float(gg.abs().max())
         assert float((gs - gg).abs().max()) <= 2e-5 * scale, (name_, float((gs - gg).abs().max()), scale)
+
+
+def test_fullsize_head_index_loss_is_additive_and_matches_aten():
+    """DifHead's loss at configs[3] (8M (node, head) rows x 8 logits, the multi-block form of disgat_cls_loss): the NLL sum over
+    all rows equals the sum over two disjoint row ranges (sums are taken in double: to 1e-12), the mean matches ATen's
+    log_softmax / NLL to fp32 accuracy, and the gradient rows sum to zero (softmax - onehot) with the right scale."""
+    from edgedisentangle_ssl_amd import ops
+    n, nh = 1_000_000, 8
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    t = (torch.randn(n * nh, nh, device="cuda", generator=gen) * 2.0).requires_grad_(True)
+    loss, logp, res = ops.cls_loss(t, None, nh, n)
+    cut = (n // 3) * nh                                   # a multiple of nh: labels stay row % nh in both parts
+    _, _, r1 = ops.cls_loss(t.detach()[:cut], None, nh, n)
+    _, _, r2 = ops.cls_loss(t.detach()[cut:], None, nh, n)
+    assert abs(float(res[0]) - float(r1[0]) - float(r2[0])) <= 1e-12 * abs(float(res[0]))
+    assert float(res[1]) == float(r1[1]) + float(r2[1])
+    ref = -torch.nn.functional.log_softmax(t.detach(), dim=1).view(-1, nh, nh).diagonal(dim1=1, dim2=2).double().sum() / n
+    assert abs(float(loss) - float(ref)) <= 2e-6 * abs(float(ref))
+    assert torch.allclose(logp[:100_000], torch.nn.functional.log_softmax(t.detach()[:100_000], dim=1), rtol=0, atol=2e-6)
+    loss.backward()
+    assert float(t.grad.sum(1).abs().max()) <= 1e-6 / n * 64
+    lab = torch.arange(nh, device="cuda").repeat(4)
+    sm = torch.softmax(t.detach()[:4 * nh], dim=1)
+    want = (sm - torch.nn.functional.one_hot(lab, nh)) / n
+    assert torch.allclose(t.grad[:4 * nh], want, rtol=1e-5, atol=1e-12)
