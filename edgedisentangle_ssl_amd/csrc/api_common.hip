@@ -7,5 +7,5 @@ char* err_buf() {
 }
 }  // namespace disgat
 
-extern "C" int disgat_abi_version(void) { return 8; }     // == _lib.ABI_VERSION: bumped with every argument-list change
+extern "C" int disgat_abi_version(void) { return 9; }     // == _lib.ABI_VERSION: bumped with every argument-list change
 extern "C" const char* disgat_last_error(void) { return disgat::err_buf(); }

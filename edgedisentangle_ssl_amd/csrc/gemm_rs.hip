@@ -295,10 +295,12 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_rs_kernel(const GemmHArgs G
 
   for (int c = 0; c < n_ch; ++c) {
     // (1) this wave's pieces of chunk c have landed: behind them in the queue are D(c+1), D(c+2) and the stores of three
-    // chunks; (2) barrier: everybody's have, and everybody is done reading chunk c-1, whose slot D(c+3) refills
+    // chunks - of two at c == 3 for waves 4-7, which retire nothing at step 0 (there the looser count would pass with D(3)
+    // still in flight); (2) barrier: everybody's have, and everybody is done reading chunk c-1, whose slot D(c+3) refills
     stamp(5);
-    if (full) rs_wait_vm<2 * P + 3 * S>();
-    else rs_wait_vm<0>();
+    if (!full || (RS_DIAG && (G.nt & 1))) rs_wait_vm<0>();      // (the no-store ablation issues no stores to count)
+    else if (late && c == 3) rs_wait_vm<2 * P + 2 * S>();
+    else rs_wait_vm<2 * P + 3 * S>();
     stamp(0);
     __builtin_amdgcn_s_barrier();
     stamp(1);

@@ -124,6 +124,28 @@ class HeadList(list):
     planes = None       # ops_gemm.Planes of the same [N, H*F_out] buffer (no-graph forwards): what FuseLayer / the DifHead
     n_heads = 0         # classifier GEMMs consume.  With `heads_planes` the fp32 buffer is never written and the list is
     f_out = 0           # EMPTY: only a consumer that asked for planes may receive such a list (DISGAT._run checks).
+    deferred = None     # DeferredHeads: the projection has NOT run yet - a FuseLayer that can take it back to back
+                        # (csrc/gemm_b2b.hip) runs projection + ELU + fuser as one launch and no head buffer ever exists;
+                        # any other consumer calls deferred.materialize(heads) first (the plane GEMM, as before).
+
+
+class DeferredHeads:
+    """The per-head output projection of a no-graph layer pass, not yet run: Z planes [H, N, F_in], the stacked weights
+    (layers.py:397-399 AT / :404-407 GCN), the optional per-head bias, the bound of the ELU output."""
+
+    def __init__(self, zp, layers, gnn, w_rm, bias, h_bound, f_in, f_out):
+        self.zp, self.layers, self.gnn, self.w_rm, self.bias, self.h_bound = zp, layers, gnn, w_rm, bias, h_bound
+        self.H, self.f_in, self.f_out = zp.shape[0], f_in, f_out
+
+    def w1_stack(self):
+        return torch.stack([l.W_em if self.gnn == "AT" else l.ag_layer.weight for l in self.layers])
+
+    def materialize(self, heads):
+        """Run the projection as the plane GEMM (head buffer written as planes only) and hang the result on `heads`."""
+        _act, hpl = ops_gemm.linear_planes(self.zp, self.w_rm, self.f_out, self.bias, None, ops_gemm.ACT_ELU, 0.01,
+                                           want_f32=False, out_bound=self.h_bound)
+        heads.planes, heads.deferred = hpl, None
+        return hpl
 
 
 MAX_HEAD_SLICE = 1024      # att 3 / 4: features of one head a single launch scores (2 heads x 32 lanes x 8 float4)
@@ -557,9 +579,16 @@ def _disga_heads(layers, x, adj, aux_indices=None, head_ranges=None, aux_only=Fa
                 wr, bias, wnorm, bnorm = _memo(layers, "proj_GCN_pl", pack_gcn_pl)
                 pre_bound = z_bound * wnorm + bnorm
             h_bound = torch.clamp(pre_bound * 1.001, min=1.0).reshape(1)     # |elu(v)| <= max(|v|, 1)
-            act, hpl = ops_gemm.linear_planes(zp, wr, f_out, bias, init, act_code, 0.01, want_f32=not heads_planes, out_bound=h_bound)
-            heads = HeadList() if act is None else HeadList(act[:, h * f_out:(h + 1) * f_out] for h in range(H))
-            heads.fused, heads.planes, heads.fused_amax = act, hpl, h_bound
+            if heads_planes and gnn in ("AT", "GCN") and ops_gemm.b2b_ok(f_in, f_out, 256):
+                # only a FuseLayer will read these heads (DISGAT._run): leave the projection to it - with a fuser width the
+                # back-to-back kernel takes, projection + ELU + fuser run as ONE launch and the head buffer never exists
+                heads = HeadList()
+                heads.deferred = DeferredHeads(zp, layers, gnn, wr, bias, h_bound, f_in, f_out)
+                heads.fused_amax = h_bound
+            else:
+                act, hpl = ops_gemm.linear_planes(zp, wr, f_out, bias, init, act_code, 0.01, want_f32=not heads_planes, out_bound=h_bound)
+                heads = HeadList() if act is None else HeadList(act[:, h * f_out:(h + 1) * f_out] for h in range(H))
+                heads.fused, heads.planes, heads.fused_amax = act, hpl, h_bound
             heads.n_heads, heads.f_out = H, f_out
             e_list = [edge_e[h].unsqueeze(1) for h in range(H)]
             zt = None
@@ -657,6 +686,18 @@ class FuseLayer(nn.Module):
                 and ops_gemm.planes_ok(self.fuse.in_features, self.fuse.out_features))
 
     def forward(self, feature_list, residue=None):
+        deferred = getattr(feature_list, "deferred", None)
+        if deferred is not None:
+            n2 = self.fuse.out_features
+            if (self.accepts_planes() and not torch.is_grad_enabled() and self.fuse.in_features == deferred.H * deferred.f_out
+                    and ops_gemm.b2b_ok(deferred.f_in, deferred.f_out, n2)):
+                # projection -> ELU -> this Linear (+ leaky_relu) back to back: one launch, no head buffer
+                act = ops_gemm.ACT_NONE if self.args.fuse_no_relu else ops_gemm.ACT_LEAKY
+                # the chunk images hold BOTH weights: memoised on the fuser and the layer's heads together
+                wch = _memo([self] + list(deferred.layers), ("b2b", deferred.gnn),
+                            lambda: ops_gemm.presplit_b2b(deferred.w1_stack(), self.fuse.weight.t()))
+                return ops_gemm.proj_fuse(deferred.zp, wch, deferred.bias, self.fuse.bias, deferred.h_bound, deferred.f_out, n2, act, 0.01)
+            deferred.materialize(feature_list)
         planes = getattr(feature_list, "planes", None)
         if planes is not None and self.accepts_planes() and not torch.is_grad_enabled():
             act = ops_gemm.ACT_NONE if self.args.fuse_no_relu else ops_gemm.ACT_LEAKY

@@ -177,6 +177,60 @@ def presplit_rm(w):
     return planes, amax_scale[1:]
 
 
+def b2b_ok(k1, n1, n2):
+    """Shapes disgat_proj_fuse takes (csrc/gemm_b2b.hip): per-head projection [k1 -> n1] + fuser [H*n1 -> n2] in one launch.
+    DISGAT_B2B=0 keeps the two-launch plane chain (same-box A/B)."""
+    return (mode() == "f16x3" and os.environ.get("DISGAT_B2B", "1") != "0" and k1 in (64, 128, 256)
+            and n1 % 32 == 0 and 64 <= n1 <= 256 and n2 in (64, 128, 256))
+
+
+_B2B_PERM = {}
+
+
+def presplit_b2b(w1, w_fuse_t):
+    """Weights of disgat_proj_fuse as ONE stream of chunk images (csrc/gemm_b2b.hip): w1 [nh, K1, N1] stacked per-head
+    projection weights, w_fuse_t = fuse.weight.t() [nh*N1, N2].  Both are split like any K <= 256 weight (fragment-major
+    planes); the fuser weight first gets the rows of every group of 32 reordered to the order a lane of GEMM 1's accumulator
+    tiles holds its columns in (position 8 q + e takes row 4 q + e for e < 4, row 16 + 4 q + e - 4 for e >= 4).  Chunk (h, j)
+    = [W1 planes x n-tiles 2j, 2j+1 x K1/32 blocks | W2 planes x N2/16 blocks of k-step j], each block 1 KB, contiguous:
+    the image a ring slot receives.  Returns (int16 [nh, N1/32, slot halfs], s1, s2)."""
+    w1 = w1.detach()
+    w2 = w_fuse_t.detach()
+    nh, k1, n1 = w1.shape
+    k2, n2 = w2.shape
+    key = (k2, w2.device)
+    idx = _B2B_PERM.get(key)
+    if idx is None:
+        kp = torch.arange(32)
+        q, e = kp >> 3, kp & 7
+        c = torch.where(e < 4, 4 * q + e, 16 + 4 * q + e - 4)
+        idx = (torch.arange(k2 // 32)[:, None] * 32 + c[None, :]).reshape(-1).to(w2.device)
+        _B2B_PERM[key] = idx
+    p1, s1 = split_weight_f16(w1)                                            # [nh, 2, N1, K1]: blocks (n / 16, k / 32)
+    p2, s2 = split_weight_f16(w2.index_select(0, idx).view(nh, n1, n2))      # [nh, 2, N2, N1]: blocks (n / 16, k / 32)
+    nj, kt, nt2 = n1 // 32, k1 // 32, n2 // 16
+    c1 = p1.view(nh, 2, nj, 2, kt, 512).permute(0, 2, 1, 3, 4, 5).reshape(nh, nj, 2 * 2 * kt * 512)
+    c2 = p2.view(nh, 2, nt2, nj, 512).permute(0, 3, 1, 2, 4).reshape(nh, nj, 2 * nt2 * 512)
+    return torch.cat([c1, c2], dim=2).contiguous(), s1, s2
+
+
+def proj_fuse(zp, w_chunks, bias1, bias2, mid_bound, n1, n2, act2=ACT_LEAKY, slope=0.01):
+    """act2(cat_h[elu(Z_h W1_h + bias1_h)] W2 + bias2) in one launch (no autograd).  zp: Planes [H, M, K1] view of the edge
+    pass's aggregate; w_chunks = presplit_b2b(W1 stack, fuse.weight.t()); mid_bound: device scalar >= max |elu(.)|."""
+    hb, m, k1 = zp.shape
+    chunks, s1, s2 = w_chunks
+    out = torch.empty((m, n2), dtype=torch.float32, device=zp.hi.device)
+    if bias1 is not None:
+        bias1 = bias1.contiguous()
+    if bias2 is not None:
+        bias2 = bias2.contiguous()
+    ops._launch("disgat_proj_fuse", "gemm_b2b", 2.0 * m * hb * n1 * (k1 + n2),
+                zp.hi.data_ptr(), zp.lo.data_ptr(), zp.hi.stride(-2), zp.hi.stride(0), zp.bound.data_ptr(),
+                chunks.data_ptr(), s1.data_ptr(), ops._ptr(bias1), s2.data_ptr(), ops._ptr(bias2),
+                mid_bound.data_ptr(), out.data_ptr(), out.stride(0), m, hb, k1, n1, n2, act2, float(slope), ops._stream())
+    return out
+
+
 def linear_planes(ap, w_rm, n, bias=None, init=None, act=ACT_NONE, slope=0.01, want_f32=True, out_bound=None):
     """act(A @ W + bias + init) with A given as Planes (no autograd: inference forwards only).  w_rm = presplit_rm(W).
     Returns (fp32 [M, H*N] or None, Planes [M, H*N] or None): the plane output (scaled by `out_bound`, a device scalar

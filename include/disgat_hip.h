@@ -79,7 +79,7 @@ extern "C" {
 
 typedef void* disgat_stream_t; /* hipStream_t */
 
-int disgat_abi_version(void);          /* 8 in this revision; changes with any launcher's argument list */
+int disgat_abi_version(void);          /* 9 in this revision; changes with any launcher's argument list */
 const char* disgat_last_error(void);
 
 /* Fused score -> sigmoid -> row softmax -> aggregation for all H heads of one layer.
@@ -324,6 +324,24 @@ int disgat_gemm_planes(const uint16_t* A_hi, const uint16_t* A_lo, int64_t lda, 
                        const float* c_bound, int M, int N, int K, int batch, int act, float slope,
                        disgat_stream_t stream);
 
+/* The per-head output projection AND the FuseLayer that consumes it as ONE launch (back-to-back GEMM; no-graph forwards):
+ *   C = act2( cat_h [ elu( Z_h W1_h + bias1_h ) ] W2 + bias2 )
+ * Z_hi / Z_lo: the aggregate as disgat_edge_fwd writes it (row m, head h at m * ldz + h * z_head_stride halfs; hi, lo of
+ * Z * s_Z, s_Z from *z_bound).  W_chunks: both weights as one stream of chunk images, [H][N1 / 32][slot]: chunk (h, j) =
+ * the disgat_split_f16 fragment blocks (1 KB each) of W1_h's columns 32 j .. 32 j + 31 - [plane][n-tile 2j, 2j+1][k-step] -
+ * followed by those of W2's rows h * N1 + 32 j .. + 31 for every column tile - [plane][n-tile] -, where W2 [H * N1][N2] is
+ * viewed as [H][N1][N2] and the rows of every group of 32 are permuted first (new position 8 q + e <- row 4 q + e for e < 4,
+ * 16 + 4 q + e - 4 for e >= 4: the order a lane of GEMM 1's accumulator tiles holds its columns in); w1_scale / w2_scale:
+ * the amax_scale + 1 of the two splits.  mid_bound: device scalar >= max |elu(.)| (the scale of the intermediate, which never
+ * leaves the registers).  bias1 [H * N1] / bias2 [N2] or NULL.  act2: 0 none, 2 leaky ReLU.
+ * K1 in {64, 128, 256}, N1 % 32 == 0 (64 <= N1 <= 256), N2 in {64, 128, 256}.
+ * Replaces layers.py:397-399 / :404-407 (+ F.elu, :508) followed by layers.py:896-921 (residue_type 0, no residue
+ * columns) for gnn_type AT / GCN - the pair disgat_gemm_planes ran as two launches through an [M][H * N1] plane buffer. */
+int disgat_proj_fuse(const uint16_t* Z_hi, const uint16_t* Z_lo, int64_t ldz, int64_t z_head_stride, const float* z_bound,
+                     const uint16_t* W_chunks, const float* w1_scale, const float* bias1, const float* w2_scale,
+                     const float* bias2, const float* mid_bound, float* C, int64_t ldc, int M, int H, int K1, int N1, int N2,
+                     int act2, float slope, disgat_stream_t stream);
+
 /* fp32 X [batch][M][K] -> planes P_hi, P_lo (hi, lo of X * s, s from *bound >= max |X|); and back:
  * X = (P_hi + P_lo * 2^-11) / s.  K and every stride multiples of 4. */
 int disgat_split_planes(const float* X, int64_t ldx, int64_t x_batch_stride, int M, int K, int batch,
@@ -339,6 +357,8 @@ int disgat_planes_to_f32(const uint16_t* P_hi, const uint16_t* P_lo, int64_t ldp
 int disgat_debug_stamps(unsigned long long* out16, int reset);
 /* The same for disgat_gemm_f16x3's register-stationary kernel (a -DRS_DIAG=1 build, DISGAT_RS_DEBUG & 32; csrc/gemm_rs.hip). */
 int disgat_debug_stamps_rs(unsigned long long* out16, int reset);
+/* The same for disgat_proj_fuse (a -DBB_DIAG=32 build, ablation bits added at compile time; csrc/gemm_b2b.hip). */
+int disgat_debug_stamps_b2b(unsigned long long* out16, int reset);
 
 /* Backward of the epilogue activation from the saved output (n contiguous floats, n % 4 == 0):
  * gin = g * (out > 0 ? 1 : (act == 1 ? out + 1 : slope)); act 1 = ELU, 2 = leaky ReLU.  gin may alias g.
