@@ -122,10 +122,11 @@ def sharded_graph(o, rank, world, dev):
     return DistGraph.from_local_edges(rows, cols, n_loc, n_glob, rank * n_loc, [n_loc] * world)
 
 
-def build_workload(o, rank, world, dev):
-    from edgedisentangle_ssl_amd import DISGAT, ops, pretrainer, sampling, synth
+def make_models(o, dev):
+    """Encoder + the three SSL trainers of the workload (reference initialisers under a fixed seed), eval mode."""
+    from edgedisentangle_ssl_amd import DISGAT, pretrainer
     a = make_args(o)
-    torch.manual_seed(0)                      # reference initialisers under a fixed seed
+    torch.manual_seed(0)
     enc = DISGAT(a, nfeat=o.feat, nhid=o.feat, nclass=o.feat, nheads=o.heads, dropout=0.0).to(dev).eval()
     enc.skip_unused = bool(o.skip_unused)
     sup = pretrainer.SupEdgeTrainer(a, enc, 1.0)
@@ -134,6 +135,12 @@ def build_workload(o, rank, world, dev):
     for tr in (sup, dis, dif):
         for m in tr.models:
             m.eval()
+    return a, enc, (sup, dis, dif)
+
+
+def build_workload(o, rank, world, dev):
+    from edgedisentangle_ssl_amd import ops, sampling, synth
+    a, enc, (sup, dis, dif) = make_models(o, dev)
     prep_ms = None
     if world == 1:
         # graph preprocessing (COO index set -> CSR + wave work items) happens once per adjacency, outside the
@@ -246,7 +253,7 @@ def cpu_model():
 def cpu_baseline(o, feat=None, gnn=None, n=None, warm=1, runs=2):
     """The oracle (CPU restatement of the reference's op sequence: kind "port") timed on this box's host cores on a
     bounded sample of the same workload: same generator, feature width, heads and attention type, fewer nodes (the
-    per-edge cost of the CPU path is flat in N: the 4x larger second sample in the bench line shows it).  SURVEY 8(d)
+    per-edge cost of the CPU path is flat in N: the 8x larger second sample in the bench line shows it).  SURVEY 8(d)
     protocol: `warm` untimed run(s), then the mean of `runs` timed ones."""
     from oracle import disgat_oracle as orc
     from edgedisentangle_ssl_amd import DISGAT, MLP, FuseLayer, synth
@@ -296,6 +303,39 @@ def cpu_baseline(o, feat=None, gnn=None, n=None, warm=1, runs=2):
             "cpu_model": cpu_model(),
             "sample": f"same generator/config, N={n} nnz={graph.nnz} F={feat} H={o.heads} att={o.att} "
                       f"gnn={gnn}, T_iter {dt:.2f}s, mean of {runs} run(s) after {warm} warm-up(s)"}
+
+
+def ops_chunk(att):
+    from edgedisentangle_ssl_amd import ops
+    return ops.CHUNK[att]
+
+
+def train_iteration(enc, trainers, graph, x, lists, timed, steps=3):
+    """ms per training iteration (SupEdge + DisEdge + DifHead: forward + backward + multi-tensor Adam, attention dropout 0.1)
+    of `enc` / `trainers` on pre-sampled lists; leaves the models in eval mode with dropout 0 again."""
+    sup, dis, dif = trainers
+    (si, sl), (hi, hl), (ti, tl) = lists
+    data = (x, graph)
+    for m in enc.modules():
+        if hasattr(m, "dropout"):
+            m.dropout = 0.1
+
+    def train():
+        for tr, fn in ((sup, lambda: sup.loss(data, sl, [si])), (dis, lambda: dis.loss(data, [hl, tl], [hi, ti])),
+                       (dif, lambda: dif.loss(data))):
+            tr._begin_step()
+            tr._finish_step(fn(), graph)
+    try:
+        return timed(train, steps)
+    finally:
+        for m in enc.modules():
+            if hasattr(m, "dropout"):
+                m.dropout = 0.0
+        for tr in trainers:
+            for m in tr.models:
+                m.eval()
+                for p_ in m.parameters():
+                    p_.grad = None
 
 
 def secondary_measurements(o, enc, trainers, graph, x, lists):
@@ -353,6 +393,23 @@ def secondary_measurements(o, enc, trainers, graph, x, lists):
         else:
             os.environ["DISGAT_GEMM"] = old_mode
         L.clear_weight_cache(enc)
+    # the reference's other attention types on the same graph, features and pair lists (utils.py:92: --att defaults to 2;
+    # layers.py:349-353, 362-365): T_iter each, and a training iteration for att 2
+    for att in (1, 2):
+        if att == o.att:
+            continue
+        oa = copy.copy(o)
+        oa.att = att
+        try:
+            graph.work_items(ops_chunk(att))
+            _a, enc_a, tr_a = make_models(oa, x.device)
+            out[f"T_iter_att{att}_ms"] = round(timed(lambda: one_step(oa, enc_a, tr_a, graph, x, lists), 3), 3)
+            if att == 2:
+                out["train_step_att2_ms"] = round(train_iteration(enc_a, tr_a, graph, x, lists, timed), 3)
+            del enc_a, tr_a
+        except (torch.OutOfMemoryError, RuntimeError) as exc:       # report, never fail the headline over a secondary number
+            out[f"T_iter_att{att}_error"] = str(exc)[:200]
+        torch.cuda.empty_cache()
     # training iteration: dropout 0.1 on, autograd on, Adam steps.  It updates the weights, so it runs LAST (after the
     # headline, the GEMM check and every other secondary number)
     sup, dis, dif = trainers
@@ -407,10 +464,11 @@ def secondary_measurements(o, enc, trainers, graph, x, lists):
                 for p_ in m.parameters():
                     p_.grad = None
     out["small_graph_epoch_ms"] = small_graph_epochs()
+    out["small_graph_epoch_ms_att2"] = small_graph_epochs(att=2, eager=False)
     return out
 
 
-def small_graph_epochs():
+def small_graph_epochs(att=3, eager=True):
     """Wall time per epoch of the reference's whole training flow (main.py:270-360: 5 CLS steps + SupEdge + DisEdge +
     DifHead train_steps, H = 8, nhid 64, att 3, dropout 0.1, Adam) on the bundled real graphs of BASELINE configs[1],
     through edgedisentangle_ssl_amd.main.run - host-bound territory.  main.run replays every train_step
@@ -425,7 +483,7 @@ def small_graph_epochs():
         fx = os.path.join(ROOT, "tests", "golden", f"data_{name}.npz")
         if not os.path.exists(fx):
             continue
-        argv = ["--model=DISGAT", "--sparse", "--dataset", name, "--fixture", fx, "--gnn_type", "AT", "--att", "3",
+        argv = ["--model=DISGAT", "--sparse", "--dataset", name, "--fixture", fx, "--gnn_type", "AT", "--att", str(att),
                 "--nhead", "8", "--nhid", "64", "--steps", "5", "--downstream", "CLS", "--down_weight", "1.0", "--finetune",
                 "--pretrain", "SupEdge", "DisEdge", "DifHead", "--pre_weight", "1", "1", "1", "--pre_edge", "1", "1", "1",
                 "--dropout", "0.1", "--seed", "4", "--quiet"]
@@ -443,12 +501,14 @@ def small_graph_epochs():
             # epochs that was +-1 ms on a 7 ms epoch, over 240 it is +-0.2
             t8, t248 = timed(8, "on"), timed(248, "on")
             res[name] = round((t248 - t8) / 240, 2)
-            e8, e68 = timed(8, "off"), timed(68, "off")
-            detail[name] = {"first_8_epochs_ms_per_epoch": round(t8 / 8, 1), "eager_ms_per_epoch": round((e68 - e8) / 60, 1)}
+            detail[name] = {"first_8_epochs_ms_per_epoch": round(t8 / 8, 1)}
+            if eager:
+                e8, e68 = timed(8, "off"), timed(68, "off")
+                detail[name]["eager_ms_per_epoch"] = round((e68 - e8) / 60, 1)
         except Exception as exc:  # noqa: BLE001  (a secondary number never fails the headline)
             res[name] = f"failed: {type(exc).__name__}: {str(exc)[:120]}"
     res["detail"] = detail
-    res["def"] = "steady-state ms per epoch of main.run (248-epoch run minus 8-epoch run, / 240), train_steps replayed from HIP graphs"
+    res["def"] = f"att {att}: steady-state ms per epoch of main.run (248-epoch run minus 8-epoch run, / 240), train_steps replayed from HIP graphs"
     return res
 
 
@@ -623,10 +683,10 @@ def main():
     cpu = None
     if not o.no_cpu_baseline and world == 1:          # rank 0, N=1 only (bench contract)
         # ~2.5 min in all on the box's 16-core share: N = 4 096 (1 warm-up + 2 timed, ~18 s each) is the reported
-        # value; one run at 4x the size shows the per-edge rate is flat in N; BASELINE configs[2]'s shape beside it
+        # value; one run at 8x the size shows the per-edge rate is flat in N; BASELINE configs[2]'s shape beside it
         cpu = cpu_baseline(o)
-        big = cpu_baseline(o, n=4 * o.cpu_nodes, warm=0, runs=1)
-        cpu["at_4x_nodes"] = {k: big[k] for k in ("value", "unit", "sample")}
+        big = cpu_baseline(o, n=8 * o.cpu_nodes, warm=0, runs=1)
+        cpu["at_8x_nodes"] = {k: big[k] for k in ("value", "unit", "sample")}
         if (o.feat, o.gnn_type) != (128, "SAGE"):
             c3 = cpu_baseline(o, feat=128, gnn="SAGE", warm=0, runs=1)
             cpu["configs2_F128_SAGE"] = {k: c3[k] for k in ("value", "unit", "sample")}

@@ -232,6 +232,72 @@ class _PackAtt3(torch.autograd.Function):
         return (None, *g_w, *g_as)
 
 
+class _PackAtt1(torch.autograd.Function):
+    """The H heads' att-1 parameters W_h [F_in, F_out], a_h [2 F_out, 1] as ONE operand of the score GEMM
+    (layers.py:349-353: e = [h_r || h_c] . a = s1[r] + s2[c], s1 = x (W a_top), s2 = x (W a_bot)):
+    wp [F_in, NP], columns [0, Hp) = W_h a_top,h, [Hp, 2 Hp) = W_h a_bot,h, the rest zero (NP = the GEMM kernels' column
+    granule, so that x @ wp runs on them instead of a 2 H-wide library GEMM at the vector rate).  All heads at once: two
+    stacks, one product + reduction - the per-head `W @ a[:F]` chain was 2 H matrix-vector launches (rocBLAS gemv) plus
+    stacks per layer and pass, 3 H more in its backward."""
+
+    @staticmethod
+    def forward(ctx, Hp, NP, *params):
+        H = len(params) // 2
+        w = torch.stack(params[:H])                                  # [H, F_in, F_out]
+        a2 = torch.stack(params[H:]).view(H, 2, 1, -1)               # [H, 2, 1, F_out]: top, bottom half of every a_h
+        s = (w.unsqueeze(1) * a2).sum(-1)                            # [H, 2, F_in]
+        wp = w.new_zeros((w.shape[1], NP))
+        wp[:, :2 * Hp].view(-1, 2, Hp)[:, :, :H] = s.permute(2, 1, 0)
+        ctx.save_for_backward(w, a2)
+        ctx.dims = (H, Hp)
+        return wp
+
+    @staticmethod
+    def backward(ctx, g):
+        w, a2 = ctx.saved_tensors
+        H, Hp = ctx.dims
+        gs = g[:, :2 * Hp].reshape(-1, 2, Hp)[:, :, :H].permute(2, 1, 0)      # [H, 2, F_in]
+        gw = (gs.unsqueeze(-1) * a2.view(H, 2, 1, -1)).sum(1)                  # [H, F_in, F_out] = sum_s gs[h,s,k] a[h,s,f]
+        ga = (gs.unsqueeze(-1) * w.unsqueeze(1)).sum(2)                         # [H, 2, F_out]   = sum_k gs[h,s,k] W[h,k,f]
+        return (None, None, *gw.unbind(0), *ga.reshape(H, -1, 1).unbind(0))
+
+
+class _PackAtt2(torch.autograd.Function):
+    """The H heads' att-2 score matrices W_h W_h^T (layers.py:362-365: e = <x_r W, x_c W> = <x_r (W W^T), x_c>) side by
+    side, [F_in, Hp * F_in_p]: ONE head-batched product on the path's own GEMM (ops_gemm: the result lands in the
+    concatenated layout), instead of H library GEMMs + pads + a cat per layer and pass.  Backward: grad W_h =
+    (G_h + G_h^T) W_h, again one batched product."""
+
+    @staticmethod
+    def forward(ctx, Hp, f_in_p, *params):
+        H = len(params)
+        w = torch.stack(params)                                      # [H, F_in, F_out]
+        f_in = w.shape[1]
+        # (weights of the bundled graphs' size: one library bmm - their steps are launch-bound and the path's own GEMM takes
+        # three preparation launches per operand)
+        small = w.numel() <= 131072
+        if small:
+            m = torch.bmm(w, w.transpose(1, 2)).permute(1, 0, 2).reshape(f_in, H * f_in)
+        else:
+            m = ops_gemm._forward(w, w.transpose(1, 2), None, None, ops_gemm.ACT_NONE, 0.0)  # [F_in, H * F_in]
+        if Hp != H or f_in_p != f_in:
+            m = F.pad(m.view(f_in, H, f_in), (0, f_in_p - f_in, 0, Hp - H)).reshape(f_in, Hp * f_in_p)
+        ctx.save_for_backward(w)
+        ctx.dims = (H, Hp, f_in, f_in_p)
+        return m
+
+    @staticmethod
+    def backward(ctx, g):
+        (w,) = ctx.saved_tensors
+        H, Hp, f_in, f_in_p = ctx.dims
+        g3 = g.view(f_in, Hp, f_in_p)[:, :H, :f_in].permute(1, 0, 2)          # [H, F_in, F_in] view
+        gs = g3 + g3.transpose(1, 2)
+        if w.numel() <= 131072:
+            return (None, None, *torch.bmm(gs, w).unbind(0))
+        gw = ops_gemm._forward(gs, w, None, None, ops_gemm.ACT_NONE, 0.0)       # [F_in, H * F_out]
+        return (None, None, *gw.view(f_in, H, -1).unbind(1))
+
+
 def _pack_score_operands(layers, x, x_all, att, H, Hp, f_in, f_out, fp, am=None, cols=None):
     """Dense, differentiable (torch ops -> MFMA GEMMs) preparation of the per-node score operands.
     x: the rows this process owns; x_all: every node a column index can name (== x unsharded).
@@ -251,10 +317,21 @@ def _pack_score_operands(layers, x, x_all, att, H, Hp, f_in, f_out, fp, am=None,
     c0, c1 = (0, f_out) if cols is None else cols
     fw = c1 - c0
     if att == 1:
-        zero = [x.new_zeros(f_in)] * (Hp - H)
-        w1 = torch.stack([l.W @ l.a[:f_out, 0] for l in layers] + zero, dim=1)     # [F_in, Hp]
-        w2 = torch.stack([l.W @ l.a[f_out:, 0] for l in layers] + zero, dim=1)
-        return x @ w1, parallel.finish(x_all) @ w2, None                           # N = Hp: too narrow for the MFMA tile
+        # one operand for both sides: s12 = x wp, s1 = columns [0, Hp), s2 = columns [Hp, 2 Hp) (strided views - the kernels
+        # take row strides); NP = 32-column granule of the K <= 256 GEMM kernel
+        NP = -(-2 * Hp // 32) * 32
+
+        def pack1():
+            wp = _PackAtt1.apply(Hp, NP, *[l.W for l in layers], *[l.a for l in layers])
+            return wp, ops_gemm.presplit(wp)
+
+        wp, sp = _memo(layers, ("att1", Hp), pack1)
+        if x_all is x:
+            s12 = ops_gemm.linear(x, wp, a_amax=am, w_split=sp)
+            return s12[:, :Hp], s12[:, Hp:2 * Hp], None
+        s_row = ops_gemm.linear(x, wp, a_amax=am, w_split=sp)                    # own rows: the gather may still be arriving
+        s_col = ops_gemm.linear(parallel.finish(x_all), wp, a_amax=am, w_split=sp)
+        return s_row[:, :Hp], s_col[:, Hp:2 * Hp], None
     if att == 4:
         # att 2 as the reference writes it (layers.py:362-365): h = x W per head, e = <h[r], h[c]>.  One operand table
         # serves both sides (column ids index the gathered x_all; unsharded, x_all is x and the GEMM runs once).
@@ -270,9 +347,13 @@ def _pack_score_operands(layers, x, x_all, att, H, Hp, f_in, f_out, fp, am=None,
         return hrow, _col_operand(x_all, wc, am, sc), None
     if att == 2:
         f_in_p = (f_in + 3) // 4 * 4
-        ms = [F.pad(l.W @ l.W.t(), (0, f_in_p - f_in)) for l in layers]
-        ms += [x.new_zeros(f_in, f_in_p)] * (Hp - H)
-        return ops_gemm.linear(x, torch.cat(ms, dim=1), a_amax=am), None, None      # [N, Hp*F_in_p]
+
+        def pack2():
+            m = _PackAtt2.apply(Hp, f_in_p, *[l.W for l in layers])
+            return m, ops_gemm.presplit(m)
+
+        m, sm = _memo(layers, ("att2", Hp, f_in_p), pack2)
+        return ops_gemm.linear(x, m, a_amax=am, w_split=sm), None, None             # [N, Hp*F_in_p]
     def pack3():
         if Hp == H and fp == fw == f_out:
             # no padding anywhere (the common case): one stack + two strided copies instead of 3 H pad / cat kernels -
@@ -371,17 +452,22 @@ class StepSeed:
 STEP_SEED = None       # set by capture.StaticStep around a step's forward + backward
 
 
-def disga_heads(layers, x, adj, aux_indices=None, head_ranges=None, aux_only=False, heads_planes=False, heads_discarded=False):
+def disga_heads(layers, x, adj, aux_indices=None, head_ranges=None, aux_only=False, heads_planes=False, heads_discarded=False,
+                heads_deferrable=False, defer_join=False):
     """All heads of one layer in fused passes: see _disga_heads (this wrapper only restores the autograd mode, which the
     implementation switches off for the tail of a layer whose per-head outputs the caller discards)."""
     prev = torch.is_grad_enabled()
     try:
-        return _disga_heads(layers, x, adj, aux_indices, head_ranges, aux_only, heads_planes, heads_discarded)
+        out = _disga_heads(layers, x, adj, aux_indices, head_ranges, aux_only, heads_planes, heads_discarded, heads_deferrable)
+        if not defer_join:
+            ops.join_side()        # (defer_join: the caller joins after its own GEMMs - DISGAT._run - so that they overlap the scorer too)
+        return out
     finally:
         torch.set_grad_enabled(prev)
 
 
-def _disga_heads(layers, x, adj, aux_indices=None, head_ranges=None, aux_only=False, heads_planes=False, heads_discarded=False):
+def _disga_heads(layers, x, adj, aux_indices=None, head_ranges=None, aux_only=False, heads_planes=False, heads_discarded=False,
+                 heads_deferrable=False):
     """All H heads of one DISGAT layer: the loop of models.py:225-228 as ONE fused edge pass.
 
     layers: the H DisGALayer modules (parameter holders).  adj: torch sparse COO or CSRGraph.
@@ -395,6 +481,8 @@ def _disga_heads(layers, x, adj, aux_indices=None, head_ranges=None, aux_only=Fa
     gradient can reach those values, the aux scores keep theirs.
     heads_planes: the caller's consumer of the heads takes ops_gemm.Planes (our FuseLayer, the DifHead classifier): on
     a no-graph forward the head buffer is then written ONLY as planes (HeadList.planes; the list itself stays empty).
+    heads_deferrable (with heads_planes): nothing but that consumer reads the heads - the projection is left to it
+    (HeadList.deferred: a FuseLayer runs projection + ELU + its own GEMM as one launch, csrc/gemm_b2b.hip).
     Returns (HeadList of elu(h') [N,F_out], [edge_e[E,1]]*H, [[aux_e[M_l,1]]_l]*H or None).
     """
     grad_mode = torch.is_grad_enabled()
@@ -500,6 +588,41 @@ def _disga_heads(layers, x, adj, aux_indices=None, head_ranges=None, aux_only=Fa
     # group, no column / feature slices, widths the kernel tiles (K = F_in a multiple of 32, 256 output columns per step)
     use_pl = (not aux_only and z_bound is not None and n_groups == 1 and len(f_slices) == 1 and f_in_p == f_in
               and f_in_p <= tile and concat and ops_gemm.planes_ok(f_in, f_out) and _no_graph(layers, x))
+    def score_aux_lists():
+        per_list = []
+        for li, pairs in enumerate(aux_indices):
+            lo, hi = (0, H) if head_ranges is None or head_ranges[li] is None else head_ranges[li]
+            per_head = [None] * H
+            if merged_aux is not None:
+                for h in range(lo, hi):
+                    per_head[h] = merged_aux[li][h].unsqueeze(1)
+                per_list.append(per_head)
+                continue
+            for gi in range(n_groups):
+                g_lo, g_hi = max(lo, gi * Hk), min(hi, (gi + 1) * Hk)      # heads of this group that are scored
+                if g_lo >= g_hi:
+                    continue
+                r, c, av, _d = group_ops(gi)
+                acfg = (att, Hk, f_in_p, fp, graph.n, g_lo - gi * Hk, g_hi - gi * Hk, rec)
+                out = ops.AuxPass.apply(xg if att == 2 else None, r, c, av, pairs, acfg)
+                if len(f_slices) > 1:          # wide heads: the other feature slices' partial scores
+                    out = torch.cat([out[: g_lo - gi * Hk],
+                                     out[g_lo - gi * Hk: g_hi - gi * Hk] + earlier_slices(gi, pairs, g_lo - gi * Hk, g_hi - gi * Hk),
+                                     out[g_hi - gi * Hk:]])
+                for h in range(g_lo, g_hi):
+                    per_head[h] = out[h - gi * Hk].unsqueeze(1)
+            per_list.append(per_head)
+        return [[per_list[li][h] for li in range(len(aux_indices))] for h in range(H)]
+
+    # No-graph forwards: the pair lists are scored NOW, on the CU-masked side stream (ops.run_on_side), beside the edge pass
+    # and the dense GEMMs that follow it in this layer and the next - they need only the score operands packed above.
+    early_aux = None
+    if (aux_indices is not None and not aux_only and not merge and ops.overlap_enabled() and _no_graph(layers, x)
+            and all(int(p.shape[1]) > 0 for p in aux_indices)):
+        ops_in = [t for so in slice_ops for t in so if t is not None] + [xg] + list(aux_indices)
+        early_aux = ops.run_on_side(score_aux_lists, ops_in)
+        ops.mark_side_outputs([t for per_head in early_aux for t in per_head if t is not None])
+
     if not aux_only:
         z_groups, e_groups = [], []
         for gi in range(n_groups):
@@ -544,7 +667,7 @@ def _disga_heads(layers, x, adj, aux_indices=None, head_ranges=None, aux_only=Fa
             e_groups.append(edge_e)
         z = z_groups[0] if n_groups == 1 else torch.cat(z_groups, dim=1)             # [N, Hp, F_in_p]
         edge_e = e_groups[0] if n_groups == 1 else torch.cat(e_groups, dim=0)        # [Hp, E]
-        if merged_aux is not None or aux_indices is None:
+        if merged_aux is not None or aux_indices is None or early_aux is not None:
             # nothing below scores anything any more: drop this frame's references to the score operands (2 x 8 GB at C4)
             # before the projection / fuser GEMMs allocate their outputs - with the rematerialising passes the operands
             # are then freed here, in inference at the latest
@@ -579,7 +702,7 @@ def _disga_heads(layers, x, adj, aux_indices=None, head_ranges=None, aux_only=Fa
                 wr, bias, wnorm, bnorm = _memo(layers, "proj_GCN_pl", pack_gcn_pl)
                 pre_bound = z_bound * wnorm + bnorm
             h_bound = torch.clamp(pre_bound * 1.001, min=1.0).reshape(1)     # |elu(v)| <= max(|v|, 1)
-            if heads_planes and gnn in ("AT", "GCN") and ops_gemm.b2b_ok(f_in, f_out, 256):
+            if heads_planes and heads_deferrable and gnn in ("AT", "GCN") and ops_gemm.b2b_ok(f_in, f_out, 256):
                 # only a FuseLayer will read these heads (DISGAT._run): leave the projection to it - with a fuser width the
                 # back-to-back kernel takes, projection + ELU + fuser run as ONE launch and the head buffer never exists
                 heads = HeadList()
@@ -631,32 +754,9 @@ def _disga_heads(layers, x, adj, aux_indices=None, head_ranges=None, aux_only=Fa
             e_list = [edge_e[h].unsqueeze(1) for h in range(H)]
 
     torch.set_grad_enabled(grad_mode)           # the aux scores below stay in the graph (heads_discarded only covers the tail above)
-    aux_out = None
-    if aux_indices is not None:
-        per_list = []
-        for li, pairs in enumerate(aux_indices):
-            lo, hi = (0, H) if head_ranges is None or head_ranges[li] is None else head_ranges[li]
-            per_head = [None] * H
-            if merged_aux is not None:
-                for h in range(lo, hi):
-                    per_head[h] = merged_aux[li][h].unsqueeze(1)
-                per_list.append(per_head)
-                continue
-            for gi in range(n_groups):
-                g_lo, g_hi = max(lo, gi * Hk), min(hi, (gi + 1) * Hk)      # heads of this group that are scored
-                if g_lo >= g_hi:
-                    continue
-                r, c, av, _d = group_ops(gi)
-                acfg = (att, Hk, f_in_p, fp, graph.n, g_lo - gi * Hk, g_hi - gi * Hk, rec)
-                out = ops.AuxPass.apply(xg if att == 2 else None, r, c, av, pairs, acfg)
-                if len(f_slices) > 1:          # wide heads: the other feature slices' partial scores
-                    out = torch.cat([out[: g_lo - gi * Hk],
-                                     out[g_lo - gi * Hk: g_hi - gi * Hk] + earlier_slices(gi, pairs, g_lo - gi * Hk, g_hi - gi * Hk),
-                                     out[g_hi - gi * Hk:]])
-                for h in range(g_lo, g_hi):
-                    per_head[h] = out[h - gi * Hk].unsqueeze(1)
-            per_list.append(per_head)
-        aux_out = [[per_list[li][h] for li in range(len(aux_indices))] for h in range(H)]
+    aux_out = early_aux
+    if aux_indices is not None and early_aux is None:
+        aux_out = score_aux_lists()
     return heads, e_list, aux_out
 
 

@@ -9,6 +9,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import ops
 from .layers import DisGALayer, FuseLayer, disga_heads
 
 
@@ -44,10 +45,12 @@ class DISGAT(nn.Module):
     # The five entry points of the reference share one two-layer loop (models.py:181-373);
     # `_run` is that loop, returning everything any of them needs.
     def _run(self, x, adj, fusers, auxiliary_edges=None, head_ranges=None, scores_only_layer2=False, heads_f32=True,
-             discard_layer2=False):
+             discard_layer2=False, heads_to_fuser_only=False):
         """heads_f32=False: the caller reads the per-head outputs only through HeadList.planes / .fused (get_em, the
         score entry points, DifHead's batched classifier) - a layer whose fuser takes planes then never writes the
-        fp32 [N, H*nhid] head buffer on a no-graph forward."""
+        fp32 [N, H*nhid] head buffer on a no-graph forward.  heads_to_fuser_only: nothing but the layer's fuser reads the
+        heads (every entry point except get_edge_em / DifHead): the projection is then left to the fuser, which may run it
+        back to back with its own GEMM (layers.DeferredHeads) - no head buffer in any form."""
         if not isinstance(fusers, list):
             fusers = [fusers]
         fu1 = self.fuser1 if not self.is_specific[0] else fusers[0]
@@ -57,38 +60,41 @@ class DISGAT(nn.Module):
             return (not heads_f32 and not torch.is_grad_enabled() and isinstance(fuser, FuseLayer) and fuser.accepts_planes())
 
         x = F.dropout(x, self.dropout, training=self.training)
-        h1, adj1, aux1 = disga_heads(self.attentions1, x, adj, auxiliary_edges, head_ranges, heads_planes=planes_only(fu1))
+        h1, adj1, aux1 = disga_heads(self.attentions1, x, adj, auxiliary_edges, head_ranges, heads_planes=planes_only(fu1),
+                                     heads_deferrable=heads_to_fuser_only, defer_join=True)
         f1 = fu1(h1, x)
         feature_1 = F.dropout(f1, self.dropout, training=self.training)
         # discard_layer2: the caller drops layer 2's heads / scores / fuser output (predict_adjs_sparse; the reference
         # computes them, models.py:319-330): computed as values only - no sign record, no graph behind them
         h2, adj2, aux2 = disga_heads(self.attentions2, feature_1, adj, auxiliary_edges, head_ranges,
                                      aux_only=scores_only_layer2, heads_planes=planes_only(fu2),
-                                     heads_discarded=discard_layer2)
+                                     heads_discarded=discard_layer2, heads_deferrable=heads_to_fuser_only, defer_join=True)
         if scores_only_layer2:
+            ops.join_side()
             return dict(x=x, feature_1=feature_1, x2=None, heads=(h1, None), adjs=(adj1, None), aux=(aux1, aux2))
         if discard_layer2:
             with torch.no_grad():
                 f2 = fu2(h2, feature_1)
         else:
             f2 = fu2(h2, feature_1)
+        ops.join_side()                 # the pair scores of both layers (run beside the layers' GEMMs on the side stream)
         return dict(x=x, feature_1=feature_1, x2=f2, heads=(h1, h2), adjs=(adj1, adj2), aux=(aux1, aux2))
 
     def forward(self, x, adj, fusers):                                   # models.py:181-214
-        return F.log_softmax(self._run(x, adj, fusers, heads_f32=False)["x2"], dim=1)
+        return F.log_softmax(self._run(x, adj, fusers, heads_f32=False, heads_to_fuser_only=True)["x2"], dim=1)
 
     def get_em(self, x, adj, fusers):                                    # models.py:217-252
-        r = self._run(x, adj, fusers, heads_f32=False)
+        r = self._run(x, adj, fusers, heads_f32=False, heads_to_fuser_only=True)
         feature_2 = F.dropout(r["x2"], self.dropout, training=self.training)
         return [r["feature_1"], feature_2]
 
     def get_adjs(self, x, adj, fusers):                                  # models.py:254-288
-        r = self._run(x, adj, fusers, heads_f32=False)
+        r = self._run(x, adj, fusers, heads_f32=False, heads_to_fuser_only=True)
         return [r["adjs"][0], r["adjs"][1]]
 
     def predict_adjs_sparse(self, x, adj, fusers, auxiliary_edges, head_ranges=None):   # models.py:290-330
         r = self._run(x, adj, fusers, auxiliary_edges, head_ranges, scores_only_layer2=self.skip_unused, heads_f32=False,
-                      discard_layer2=True)
+                      discard_layer2=True, heads_to_fuser_only=True)
         return [r["aux"][0], r["aux"][1]]
 
     def get_edge_em(self, x, adj, fusers):                               # models.py:333-373

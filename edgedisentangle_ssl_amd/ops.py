@@ -92,6 +92,93 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# ---- side stream for the pair scorer (no-graph forwards).  Inside one encoder pass the aux scorer of layer l depends only
+# on that layer's score operands (P_l, Q_l) and nobody reads its scores before the loss, while the chain the next layer
+# waits for - edge pass -> projection + fuser -> P_{l+1}, Q_{l+1} - is half dense GEMMs that leave HBM idle.  The scorer is
+# HBM-bound (6.3 TB/s with every wave slot of the chip taken), so launched beside them on an ordinary stream it fills every
+# CU and the GEMM workgroups wait for one to drain (round 4's three-stream experiment: -1.5 %).  Here it runs on a stream
+# whose CU MASK leaves a share of the chip's CUs to the main stream (hipExtStreamCreateWithCUMask).  DISGAT_OVERLAP=0
+# switches it off; DISGAT_SIDE_CUS = the share of CUs the scorer may use (default 0.75).
+_SIDE = {}
+_SIDE_PENDING = []
+
+
+def overlap_enabled():
+    import os
+    return (os.environ.get("DISGAT_OVERLAP", "1") != "0" and not torch.is_grad_enabled()
+            and not torch.cuda.is_current_stream_capturing())
+
+
+def side_stream(dev=None):
+    """The CU-masked stream of `dev` (created once per device and share); None when the runtime refuses a mask."""
+    import ctypes
+    import os
+    dev = torch.cuda.current_device() if dev is None else torch.device(dev).index
+    share = float(os.environ.get("DISGAT_SIDE_CUS", "0.75"))
+    key = (dev, share)
+    if key in _SIDE:
+        return _SIDE[key]
+    stream = None
+    try:
+        n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+        words = (n_cu + 31) // 32
+        mask = (ctypes.c_uint32 * words)()
+        period = 8
+        keep = max(1, min(period, round(share * period)))
+        # the CUs left out are spread evenly whether CU ids run XCD by XCD or round-robin over the XCDs
+        for i in range(n_cu):
+            if ((i // 8) + i) % period < keep:
+                mask[i // 32] |= 1 << (i % 32)
+        hip = ctypes.CDLL("libamdhip64.so")
+        ptr = ctypes.c_void_p()
+        with torch.cuda.device(dev):
+            rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(ptr), ctypes.c_uint32(words), mask)
+        if rc == 0 and ptr.value:
+            stream = torch.cuda.ExternalStream(ptr.value, device=dev)
+    except (OSError, AttributeError, RuntimeError):
+        stream = None
+    _SIDE[key] = stream
+    return stream
+
+
+def run_on_side(fn, inputs):
+    """fn() on the side stream once everything the current stream has queued so far is done (its inputs are ready);
+    `inputs`: the tensors fn reads (kept from reuse by the allocator until the side stream is through with them).  Returns
+    fn's result; its tensors may be READ on the current stream only after join_side().  Falls back to a plain call."""
+    side = side_stream()
+    if side is None:
+        return fn()
+    main = torch.cuda.current_stream()
+    ready = torch.cuda.Event()
+    ready.record(main)
+    side.wait_event(ready)
+    for t in inputs:
+        if t is not None:
+            t.record_stream(side)
+    with torch.cuda.stream(side):
+        out = fn()
+        done = torch.cuda.Event()
+        done.record(side)
+    _SIDE_PENDING.append((done, main))
+    return out
+
+
+def mark_side_outputs(tensors):
+    """Outputs of run_on_side that the current stream will read after join_side(): allocated on the side stream's pool."""
+    main = torch.cuda.current_stream()
+    for t in tensors:
+        if t is not None:
+            t.record_stream(main)
+
+
+def join_side():
+    """The current stream waits for everything run_on_side has queued."""
+    cur = torch.cuda.current_stream()
+    while _SIDE_PENDING:
+        done, _main = _SIDE_PENDING.pop()
+        cur.wait_event(done)
+
+
 def _check(t, name, dtype=torch.float32):
     if not t.is_cuda:
         raise RuntimeError(f"{name}: the DISGAT HIP path needs device tensors (got {t.device}); no CPU fallback exists")

@@ -554,8 +554,9 @@ TINY256 = dict(n=2048, e=40960, f=256, nhid=256, heads=4)
 def gen_tiny256():
     """A fixture at a width the plane-operand GEMM chain tiles (nhid 64 on the bundled graphs never engages
     csrc/gemm_planes.hip, so the chain bench.py times had only met the float64 oracle): SURVEY 8(d)'s power-law generator
-    at N = 2 048 / E = 40 960, F_in = nhid = 256, H = 4, att 3, AT and SAGE - the reference's five entry points and three
-    losses; 256-row slices, column sums and strided score samples are kept."""
+    at N = 2 048 / E = 40 960, F_in = nhid = 256, H = 4 - att 3 with AT, SAGE and (round 5) GCN, and the reference's default
+    attention type, att 2, with AT - the reference's five entry points and three losses; 256-row slices, column sums and
+    strided score samples are kept.  Fixtures already on disk are left alone (they stay byte-identical)."""
     c = TINY256
     n = c["n"]
     idx = ic.powerlaw_index(1234, n, c["e"])
@@ -567,9 +568,11 @@ def gen_tiny256():
     sup_idx, sup_lab = ic.sample_pairs(81, n, pos, "sup")
     ho_idx, ho_lab = ic.sample_pairs(82, n, homo, "homo")
     he_idx, he_lab = ic.sample_pairs(83, n, het, "het")
-    for gnn in ("AT", "SAGE"):
+    for gnn, att in (("AT", 3), ("SAGE", 3), ("GCN", 3), ("AT", 2)):
+        if os.path.exists(os.path.join(GOLD, f"tiny256_{gnn}_att{att}.npz")):
+            continue
         full = {}
-        run_case(x, adj, n, labels, gnn, 3, c["heads"], c["nhid"], 400, [sup_idx], (sup_lab, [sup_idx]),
+        run_case(x, adj, n, labels, gnn, att, c["heads"], c["nhid"], 400, [sup_idx], (sup_lab, [sup_idx]),
                  ([ho_lab, he_lab], [ho_idx, he_idx]), False, full)
         out = {k: full[k] for k in ("loss_sup", "loss_dis", "loss_dif")}
         for k in ("forward", "get_em_0", "get_em_1"):
@@ -583,8 +586,8 @@ def gen_tiny256():
             out[f"aux_{l}_0_sum"] = full[f"aux_{l}_0"].astype(np.float64).sum(1)
             out[f"edge_em_{l}_head"] = full[f"edge_em_{l}"][:, :64]
             out[f"edge_em_{l}_sum"] = full[f"edge_em_{l}"].astype(np.float64).sum((1, 2))
-        np.savez_compressed(os.path.join(GOLD, f"tiny256_{gnn}_att3.npz"), **out)
-        print("tiny256", gnn, "nnz", ci.shape[1], "M", sup_idx.shape[1], "sum_em0 %.6e sup %.8f dis %.8f dif %.6f" % (
+        np.savez_compressed(os.path.join(GOLD, f"tiny256_{gnn}_att{att}.npz"), **out)
+        print("tiny256", gnn, "att", att, "nnz", ci.shape[1], "M", sup_idx.shape[1], "sum_em0 %.6e sup %.8f dis %.8f dif %.6f" % (
             full["get_em_0"].sum(), out["loss_sup"], out["loss_dis"], out["loss_dif"]))
 
 

@@ -99,7 +99,8 @@ def test_b2b_forward_equals_two_launch_chain(gnn, monkeypatch):
     x = synth.features(n, 256, dev)
     enc = DISGAT(a, nfeat=256, nhid=256, nclass=256, nheads=4, dropout=0.0).to(dev).eval()
     sup = pretrainer.SupEdgeTrainer(a, enc, 1.0)
-    for m_ in sup.models:
+    dif = pretrainer.DifHeadTrainer(a, enc, 1.0)
+    for m_ in sup.models + dif.models:
         m_.eval()
     (si, sl), _, _ = synth.ssl_lists(graph, synth.node_labels(n, dev))
     calls = []
@@ -117,15 +118,19 @@ def test_b2b_forward_equals_two_launch_chain(gnn, monkeypatch):
         with torch.no_grad():
             em = enc.get_em(x, graph, [sup.fuse1, sup.fuse2])
             aux = enc.predict_adjs_sparse(x, graph, [sup.fuse1, sup.fuse2], [si])
-        return em, aux
+            # DifHead's classifier reads the heads too: its pass keeps the head planes (no deferral), whatever the switch says
+            n0 = len(calls)
+            dl = dif.loss((x, graph))
+            assert "disgat_proj_fuse" not in calls[n0:]
+        return em, aux, float(dl)
     monkeypatch.setenv("DISGAT_B2B", "1")
-    em1, aux1 = run()
+    em1, aux1, dl1 = run()
     n_b2b = calls.count("disgat_proj_fuse")
-    assert n_b2b == 4 and "disgat_gemm_planes" not in calls, calls
+    assert n_b2b == 4, calls
     calls.clear()
     monkeypatch.setenv("DISGAT_B2B", "0")
-    em0, aux0 = run()
-    assert "disgat_proj_fuse" not in calls and calls.count("disgat_gemm_planes") == 8
+    em0, aux0, dl0 = run()
+    assert "disgat_proj_fuse" not in calls and dl1 == dl0
     for l in range(2):
         sc = float(em0[l].abs().max())
         assert float((em1[l] - em0[l]).abs().max()) <= 2e-6 * max(1.0, sc)

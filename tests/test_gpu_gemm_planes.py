@@ -140,13 +140,15 @@ def test_foreign_fuser_still_receives_fp32_heads():
     assert all(ln == H for _t, ln in seen) and torch.isfinite(out[1]).all()
 
 
-@pytest.mark.parametrize("gnn", ["AT", "SAGE"])
-def test_plane_chain_meets_a_reference_output(gnn, golden_dir):
+@pytest.mark.parametrize("gnn,att", [("AT", 3), ("SAGE", 3), ("GCN", 3), ("AT", 2)])
+def test_plane_chain_meets_a_reference_output(gnn, att, golden_dir):
     """the plane-operand chain (edge pass -> Z planes -> projection -> head planes -> fuser / DifHead
     classifier) never engages at the bundled graphs' nhid = 64, so it had only met the float64 oracle.  tiny256_*.npz holds
     the UNMODIFIED reference's outputs at a width the chain tiles (SURVEY 8(d)'s generator, N = 2 048, F_in = nhid = 256,
-    H = 4, att 3; oracle/gen_golden.py --only tiny256): the five entry points and the three losses at north_star's 1e-4,
-    with the launcher counted to prove the chain ran."""
+    H = 4; oracle/gen_golden.py --only tiny256): the five entry points and the three losses at north_star's 1e-4, with the
+    launchers counted to prove the chain ran.  Round 5: GCN, and att 2 - the reference's argparse default (utils.py:92); for
+    AT / GCN the projection + fuser pair of forward / get_em / the score entry points is the back-to-back launch
+    (disgat_proj_fuse), DifHead keeps the plane GEMMs (its classifier reads the heads too)."""
     import os
     import numpy as np
     import inputs_common as ic
@@ -154,7 +156,7 @@ def test_plane_chain_meets_a_reference_output(gnn, golden_dir):
     from test_gpu_parity import TOL, build, close
     from test_gpu_backward import _trainers
     dev = torch.device("cuda:0")
-    g = np.load(os.path.join(golden_dir, f"tiny256_{gnn}_att3.npz"))
+    g = np.load(os.path.join(golden_dir, f"tiny256_{gnn}_att{att}.npz"))
     n, e, f, heads = 2048, 40960, 256, 4
     idx = ic.powerlaw_index(1234, n, e)
     ci = ic.coalesced_index_set(idx, n)
@@ -165,7 +167,7 @@ def test_plane_chain_meets_a_reference_output(gnn, golden_dir):
     sup = [t.to(dev) for t in ic.sample_pairs(81, n, pos, "sup")]
     ho = [t.to(dev) for t in ic.sample_pairs(82, n, homo, "homo")]
     he = [t.to(dev) for t in ic.sample_pairs(83, n, het, "het")]
-    a, enc, fus = build(gnn, 3, heads, f, f, 400, dev)
+    a, enc, fus = build(gnn, att, heads, f, f, 400, dev)
     calls = {}
     real_call = _lib.call
 
@@ -177,7 +179,8 @@ def test_plane_chain_meets_a_reference_output(gnn, golden_dir):
         with torch.no_grad():
             fwd = enc(x, adj, fus)
             em = enc.get_em(x, adj, fus)
-            n_planes = calls.get("disgat_gemm_planes", 0)
+            n_planes = calls.get("disgat_gemm_planes", 0) + 2 * calls.get("disgat_proj_fuse", 0)
+            assert (calls.get("disgat_proj_fuse", 0) >= 4) == (gnn in ("AT", "GCN")), calls
             adjs = enc.get_adjs(x, adj, fus)
             auxs = enc.predict_adjs_sparse(x, adj, fus, [sup[0]])
             eem = enc.get_edge_em(x, adj, fus)
