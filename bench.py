@@ -608,6 +608,10 @@ def main():
         rank = dist.get_rank()
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    if os.environ.get("DISGAT_OVERLAP") == "1":
+        # the side-stream experiment (ops.overlap_enabled; off by default): needs a stream of our own - the legacy default
+        # stream synchronises with every blocking stream, the CU-masked side stream of the pair scorer among them
+        torch.cuda.set_stream(torch.cuda.Stream(dev))
 
     from edgedisentangle_ssl_amd import _lib, ops
     _lib.load()

@@ -97,15 +97,27 @@ def _stream():
 # waits for - edge pass -> projection + fuser -> P_{l+1}, Q_{l+1} - is half dense GEMMs that leave HBM idle.  The scorer is
 # HBM-bound (6.3 TB/s with every wave slot of the chip taken), so launched beside them on an ordinary stream it fills every
 # CU and the GEMM workgroups wait for one to drain (round 4's three-stream experiment: -1.5 %).  Here it runs on a stream
-# whose CU MASK leaves a share of the chip's CUs to the main stream (hipExtStreamCreateWithCUMask).  DISGAT_OVERLAP=0
-# switches it off; DISGAT_SIDE_CUS = the share of CUs the scorer may use (default 0.75).
+# whose CU MASK leaves a share of the chip's CUs to the main stream (hipExtStreamCreateWithCUMask).
+# MEASURED AND LEFT OFF (DISGAT_OVERLAP=1 enables it; DISGAT_SIDE_CUS = the scorer's share of the CUs): T_iter 553-578 ms
+# sequential against 566 / 667 / 714 / 618 ms at shares 0.75 / 0.625 / 0.875 / 0.5, with single runs at 1.86 s
+# (gpurun_out/r05/bench_overlap_2.log).  The kernels do run side by side then - the edge pass takes 1.65x, the back-to-back
+# GEMM 3.5x its time alone: a workgroup of it needs a CU's whole register file (512 registers x 4 waves), so it is placed
+# only on CUs the scorer's mask leaves EMPTY, i.e. on a quarter of the chip, and what it gains from the idle HBM cycles it
+# loses to running on 64 CUs; meanwhile the edge pass of the same chain shares the HBM with the scorer and finishes later.
+# The step is at 94 % of its all-traffic floor; no split of the chip between an HBM-bound and a CU-hungry kernel beat the
+# sequential order.
 _SIDE = {}
 _SIDE_PENDING = []
 
 
 def overlap_enabled():
+    """The masked stream is a BLOCKING stream (hipExtStreamCreateWithCUMask takes no flags): it and the legacy default stream
+    wait for each other's work, so beside the default stream nothing overlaps and the scorer only loses CUs (measured: 548 ->
+    605-628 ms).  The overlap therefore engages only when the caller runs on a stream of its own (torch.cuda.set_stream /
+    with torch.cuda.stream(...): bench.py and main.run do)."""
     import os
-    return (os.environ.get("DISGAT_OVERLAP", "1") != "0" and not torch.is_grad_enabled()
+    return (os.environ.get("DISGAT_OVERLAP", "0") == "1" and not torch.is_grad_enabled()
+            and torch.cuda.current_stream() != torch.cuda.default_stream()
             and not torch.cuda.is_current_stream_capturing())
 
 
