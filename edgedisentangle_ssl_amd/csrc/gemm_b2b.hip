@@ -25,7 +25,11 @@
 // tools/b2b_stamps.py).  So the instruction stream is laid out by hand: per group of 12 MFMAs the next group's four
 // ds_read_b128 sit one by one in the first MFMA gaps (counted lgkmcnt waits in front of each fragment's first use), one DMA
 // piece of the next chunk in the tail; every statement is pinned by sched_barrier.
-// Arithmetic per chunk and wave: 96 + 96 MFMAs (16x16x32 f16), 64 ds_read_b128, 16 DMA pieces, ~200 vector instructions.
+// The ELU / scale / split arithmetic of a chunk (~150 vector instructions, 800 cycles when they stood alone between the two
+// GEMMs) runs UNDER matrix work: GEMM 2 is one chunk behind - step s is [GEMM 1 (s)] [GEMM 2 (s-1) with the arithmetic of
+// chunk s, two or three instructions at a time, in its MFMA gaps], the intermediate of chunk s-1 waiting in 16 registers.
+// Step 0 runs GEMM 2 on a zero intermediate; GEMM 2 of the last chunk follows the loop.
+// Arithmetic per chunk and wave: 96 + 96 MFMAs (16x16x32 f16), 64 ds_read_b128, 16 DMA pieces, ~150 vector instructions.
 // HBM: the Z planes once (8.2 GB) + 1 GB of output; the head buffer's 16.4 GB round trip is gone.
 #include <stdlib.h>
 #include <type_traits>
@@ -163,9 +167,11 @@ __global__ __launch_bounds__(256, 1) void proj_fuse_kernel(const B2BArgs G) {
   unsigned char* const ring_w = lds_bb + wave * 1024;
   auto chunk_src = [&](int h, int j) __attribute__((always_inline)) { return wc + (int64_t)(h * nj + j) * SLOT; };
   {
+    // chunk 0: its W1 part into slot 0; its W2 part into slot 1 - what step 0's GEMM 2 multiplies its ZERO intermediate
+    // with (any finite image does); step 0 then requests W1 of chunk 1 and W2 of chunk 0 like every step
     const unsigned char* src = chunk_src(head_of(0), 0);
 #pragma unroll
-    for (int i = 0; i < NP; ++i) bb_glds16(src + i * 4096, ring_w + i * 4096);
+    for (int i = 0; i < NP; ++i) bb_glds16(src + i * 4096, ring_w + (i < KT ? 0 : SLOT) + i * 4096);
   }
   if constexpr (BIAS1) {
     // GEMM 1's bias through LDS: a global load inside the loop would sit behind the chunk's DMA pieces in the in-order
@@ -203,6 +209,14 @@ __global__ __launch_bounds__(256, 1) void proj_fuse_kernel(const B2BArgs G) {
     }
   }
 
+  // the intermediate of the PREVIOUS chunk, GEMM 2's operand this step (fragments [row tile]: hi, lo)
+  f16x8 mh[2], ml[2];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) {
+    mh[rt] = __builtin_bit_cast(f16x8, u32x4{0u, 0u, 0u, 0u});
+    ml[rt] = __builtin_bit_cast(f16x8, u32x4{0u, 0u, 0u, 0u});
+  }
+
   // LDS byte address of slot 0 + the lane's 16 bytes of a fragment block
   const uint32_t sa0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) unsigned char*)(lds_bb) + lane * 16;
 
@@ -219,20 +233,99 @@ __global__ __launch_bounds__(256, 1) void proj_fuse_kernel(const B2BArgs G) {
   };
   stamp(-1);
 
+  constexpr std::integral_constant<int, 0> c0{};
+  constexpr std::integral_constant<int, 1> c1{};
+  constexpr std::integral_constant<int, 2> c2{};
+  constexpr std::integral_constant<int, 3> c3{};
+  // A group: 12 MFMAs on fragments cur[0..3] - MFMA i uses cur[0], cur[0], cur[1], cur[1] (hi x hi), cur[2], cur[2], cur[3],
+  // cur[3] (lo x hi), cur[0], cur[0], cur[1], cur[1] (hi x lo) - with the NEXT group's four reads in the first four gaps
+  // and the waits counted on what is outstanding in issue order: [c0 c1 c2 c3] at entry, then n0, n1 behind M0, M1, ...
+  //   W(c0) M0 R(n0) M1 R(n1) W(c1) M2 R(n2) M3 R(n3) W(c2) M4 g M5 g W(c3) M6 g M7 g M8 [tail] g M9 g M10 g M11 g
+  // (g: a gap the caller may fill - GEMM 2 puts the ELU / split arithmetic there)
+  auto group = [&](f16x8(&cur)[4], auto has_next_c, auto&& mfma, auto&& rdn, auto&& tail, auto&& gap) __attribute__((always_inline)) {
+    constexpr bool HN = decltype(has_next_c)::value;
+    bb_lw<3>(cur[0]);
+    mfma(c0, cur[0]); BB_PIN;
+    if constexpr (HN) { rdn(c0); BB_PIN; }
+    mfma(c1, cur[0]); BB_PIN;
+    if constexpr (HN) { rdn(c1); BB_PIN; }
+    bb_lw<HN ? 4 : 2>(cur[1]);
+    mfma(c2, cur[1]); BB_PIN;
+    if constexpr (HN) { rdn(c2); BB_PIN; }
+    mfma(c3, cur[1]); BB_PIN;
+    if constexpr (HN) { rdn(c3); BB_PIN; }
+    bb_lw<HN ? 5 : 1>(cur[2]);
+    mfma(std::integral_constant<int, 4>{}, cur[2]); BB_PIN;
+    gap(c0);
+    mfma(std::integral_constant<int, 5>{}, cur[2]); BB_PIN;
+    gap(c1);
+    bb_lw<HN ? 4 : 0>(cur[3]);
+    mfma(std::integral_constant<int, 6>{}, cur[3]); BB_PIN;
+    gap(c2);
+    mfma(std::integral_constant<int, 7>{}, cur[3]); BB_PIN;
+    gap(c3);
+    mfma(std::integral_constant<int, 8>{}, cur[0]); BB_PIN;
+    tail();
+    gap(std::integral_constant<int, 4>{});
+    mfma(std::integral_constant<int, 9>{}, cur[0]); BB_PIN;
+    gap(std::integral_constant<int, 5>{});
+    mfma(std::integral_constant<int, 10>{}, cur[1]); BB_PIN;
+    gap(std::integral_constant<int, 6>{});
+    mfma(std::integral_constant<int, 11>{}, cur[1]); BB_PIN;
+    gap(std::integral_constant<int, 7>{});
+  };
+  auto no_gap = [&](auto) __attribute__((always_inline)) {};
+
+  // GEMM 2's fragments of column tiles 2 np, 2 np + 1 out of the W2 part of the slot at LDS address `sap`
+  auto rd2 = [&](uint32_t sap, f16x8(&d)[4], auto nc, auto kc) __attribute__((always_inline)) {
+    constexpr int np = decltype(nc)::value, k = decltype(kc)::value;
+    bb_rd<W1_PART + (k >> 1) * W2_PLANE + (2 * np + (k & 1)) * 1024>(d[k], sap);
+  };
+  // GEMM 2 on the intermediate mh / ml: the chunk's k-step of [32 rows] x [N2], two column tiles per group; the fragments of
+  // group 0 are already requested into fr[G1 & 1]; gapf(np, k) / tailf(np): what the caller puts into the groups' gaps
+  auto gemm2 = [&](uint32_t sap, f16x8(&fr)[2][4], auto&& gapf, auto&& tailf) __attribute__((always_inline)) {
+    bb_static_for<G2>([&](auto nc) __attribute__((always_inline)) {
+      constexpr int np = decltype(nc)::value;
+      f16x8(&cur)[4] = fr[(G1 + np) & 1];
+      f16x8(&nxt)[4] = fr[(G1 + np + 1) & 1];
+      auto mfma = [&](auto ic, f16x8& w) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value, rt = i & 1, c = (i >> 1) & 1, ph = i >> 2, nt = 2 * np + c;
+        if constexpr ((BB_DIAG & 8) != 0) {
+          asm volatile("" ::"v"(w));
+        } else if constexpr (ph == 0) {
+          acc2[rt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w, mh[rt], acc2[rt][nt], 0, 0, 0);
+        } else if constexpr (ph == 1) {
+          acx2[rt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w, mh[rt], acx2[rt][nt], 0, 0, 0);
+        } else {
+          acx2[rt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w, ml[rt], acx2[rt][nt], 0, 0, 0);
+        }
+      };
+      auto rdn = [&](auto kc) __attribute__((always_inline)) { rd2(sap, nxt, std::integral_constant<int, (np + 1 < G2 ? np + 1 : 0)>{}, kc); };
+      auto tail = [&]() __attribute__((always_inline)) { tailf(nc); };
+      auto gap = [&](auto kc) __attribute__((always_inline)) { gapf(nc, kc); };
+      if constexpr (np + 1 < G2) group(cur, std::true_type{}, mfma, rdn, tail, gap);
+      else group(cur, std::false_type{}, mfma, rdn, tail, gap);
+    });
+  };
+
   // One chunk.  first: a head's first chunk after a LAST step; LAST: the head's last chunk - the next head's Z fragments
   // are requested k-step by k-step as its GEMM 1 retires this head's, behind ALL of the next chunk's DMA pieces (which a
   // LAST step therefore issues up front), so that the next step's counted wait can tell the two apart.
   auto step = [&](int s, int h, int j, int h_next, bool first, auto last_c) __attribute__((always_inline)) {
     constexpr bool LAST = decltype(last_c)::value;
     const int slot = s & 1;
-    // the next chunk's image (the very last step re-requests its own chunk into the idle slot: the stream stays branch-free)
-    const unsigned char* nsrc = LAST ? (h_next >= 0 ? chunk_src(h_next, 0) : chunk_src(h, j)) : chunk_src(h, j + 1);
+    // this step requests W1 of the NEXT chunk (into the other slot, whose W1 part GEMM 1 of step s-1 has left) and W2 of ITS
+    // OWN chunk (into this slot, whose W2 part GEMM 2 of step s-1 has left: it held chunk s-2's); the last step re-requests
+    // its own W1: the stream stays branch-free
+    const unsigned char* csrc = chunk_src(h, j);
+    const unsigned char* nsrc = LAST ? (h_next >= 0 ? chunk_src(h_next, 0) : csrc) : chunk_src(h, j + 1);
     unsigned char* ndst = ring_w + (slot ^ 1) * SLOT;
+    unsigned char* cdst = ring_w + slot * SLOT;
     constexpr bool refill = !(BB_DIAG & 1);
     auto dma = [&](auto ic) __attribute__((always_inline)) {
       constexpr int i = decltype(ic)::value;
       if constexpr (i < NP) {
-        if constexpr (refill) bb_glds16(nsrc + i * 4096, ndst + i * 4096);
+        if constexpr (refill) bb_glds16((i < KT ? nsrc : csrc) + i * 4096, (i < KT ? ndst : cdst) + i * 4096);
         BB_PIN;
       }
     };
@@ -264,7 +357,8 @@ __global__ __launch_bounds__(256, 1) void proj_fuse_kernel(const B2BArgs G) {
     }
     bb_fence8(acc1, acx1, false);
     BB_PIN;
-    const uint32_t sa = sa0 + slot * SLOT;
+    const uint32_t sa = sa0 + slot * SLOT;                 // W1 of this chunk
+    const uint32_t sa_prev = sa0 + (slot ^ 1) * SLOT;      // W2 of the previous chunk
     // LAST: the next head's Z fragments of k-step t into the registers of this head's (retired by GEMM 1 group t).  A
     // workgroup's 128 KB arrive at the CU's fetch rate (~45 GB/s measured: 2.8 us) and a wave whose vector-memory queue is
     // full stalls at the next issue - requested group by group during GEMM 1 they stopped its MFMA stream for ~5.7 k cycles
@@ -289,49 +383,12 @@ __global__ __launch_bounds__(256, 1) void proj_fuse_kernel(const B2BArgs G) {
       constexpr int t = decltype(tc)::value, k = decltype(kc)::value;
       bb_rd<(k >> 1) * W1_PLANE + ((k & 1) * KT + t) * 1024>(d[k], sa);
     };
-    auto rd2 = [&](f16x8(&d)[4], auto nc, auto kc) __attribute__((always_inline)) {
-      constexpr int np = decltype(nc)::value, k = decltype(kc)::value;
-      bb_rd<W1_PART + (k >> 1) * W2_PLANE + (2 * np + (k & 1)) * 1024>(d[k], sa);
-    };
-    constexpr std::integral_constant<int, 0> c0{};
-    constexpr std::integral_constant<int, 1> c1{};
-    constexpr std::integral_constant<int, 2> c2{};
-    constexpr std::integral_constant<int, 3> c3{};
     rd1(f[0], c0, c0);
     rd1(f[0], c0, c1);
     rd1(f[0], c0, c2);
     rd1(f[0], c0, c3);
     BB_PIN;
     stamp(2);
-
-    // A group: 12 MFMAs on fragments cur[0..3] - MFMA i uses cur[0], cur[0], cur[1], cur[1] (hi x hi), cur[2], cur[2], cur[3],
-    // cur[3] (lo x hi), cur[0], cur[0], cur[1], cur[1] (hi x lo) - with the NEXT group's four reads in the first four gaps
-    // and the waits counted on what is outstanding in issue order: [c0 c1 c2 c3] at entry, then n0, n1 behind M0, M1, ...
-    //   W(c0) M0 R(n0) M1 R(n1) W(c1) M2 R(n2) M3 R(n3) W(c2) M4 M5 W(c3) M6 M7 M8 [tail] M9 M10 M11
-    auto group = [&](f16x8(&cur)[4], auto has_next_c, auto&& mfma, auto&& rdn, auto&& tail) __attribute__((always_inline)) {
-      constexpr bool HN = decltype(has_next_c)::value;
-      bb_lw<3>(cur[0]);
-      mfma(c0, cur[0]); BB_PIN;
-      if constexpr (HN) { rdn(c0); BB_PIN; }
-      mfma(c1, cur[0]); BB_PIN;
-      if constexpr (HN) { rdn(c1); BB_PIN; }
-      bb_lw<HN ? 4 : 2>(cur[1]);
-      mfma(c2, cur[1]); BB_PIN;
-      if constexpr (HN) { rdn(c2); BB_PIN; }
-      mfma(c3, cur[1]); BB_PIN;
-      if constexpr (HN) { rdn(c3); BB_PIN; }
-      bb_lw<HN ? 5 : 1>(cur[2]);
-      mfma(std::integral_constant<int, 4>{}, cur[2]); BB_PIN;
-      mfma(std::integral_constant<int, 5>{}, cur[2]); BB_PIN;
-      bb_lw<HN ? 4 : 0>(cur[3]);
-      mfma(std::integral_constant<int, 6>{}, cur[3]); BB_PIN;
-      mfma(std::integral_constant<int, 7>{}, cur[3]); BB_PIN;
-      mfma(std::integral_constant<int, 8>{}, cur[0]); BB_PIN;
-      tail();
-      mfma(std::integral_constant<int, 9>{}, cur[0]); BB_PIN;
-      mfma(std::integral_constant<int, 10>{}, cur[1]); BB_PIN;
-      mfma(std::integral_constant<int, 11>{}, cur[1]); BB_PIN;
-    };
 
     bb_static_for<G1>([&](auto tc) __attribute__((always_inline)) {
       constexpr int t = decltype(tc)::value;
@@ -355,73 +412,96 @@ __global__ __launch_bounds__(256, 1) void proj_fuse_kernel(const B2BArgs G) {
       // the next group's fragments: the next k-step's, or - behind the last k-step - GEMM 2's first two column tiles
       auto rdn = [&](auto kc) __attribute__((always_inline)) {
         if constexpr (t + 1 < G1) rd1(nxt, std::integral_constant<int, (t + 1 < G1 ? t + 1 : 0)>{}, kc);
-        else rd2(nxt, c0, kc);
+        else rd2(sa_prev, nxt, c0, kc);
       };
       auto tail = [&]() __attribute__((always_inline)) {
         if constexpr (!LAST) bb_static_for<PP>([&](auto pc) __attribute__((always_inline)) { dma(std::integral_constant<int, t * PP + decltype(pc)::value>{}); });
       };
-      group(cur, std::true_type{}, mfma, rdn, tail);
+      group(cur, std::true_type{}, mfma, rdn, tail, no_gap);
       if constexpr (t < ZG1) z_req(tc);
     });
 
-    // ---- ELU, scale, hi / lo split: the chunk as GEMM 2's operand fragments (element e of lane (r, q): column 4 q + e of
-    // tile 0 for e < 4, of tile 1 for e >= 4 - the order W2's rows were permuted to)
+    // ---- ELU, scale, hi / lo split of THIS chunk: 64 micro-steps (8 value pairs x 8 stages of two or three instructions)
+    // that GEMM 2 of the previous chunk places in its MFMA gaps.  Element e of lane (r, q) of the resulting fragments:
+    // column 4 q + e of tile 0 for e < 4, of tile 1 for e >= 4 - the order W2's rows were permuted to.
     bb_fence8(acc1, acx1, true);
     stamp(3);
-    f16x8 mh[2], ml[2];
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
-      f32x4 v[2];
+    float ev[8][2], ee[8][2];
+    uint32_t ehp[8], elp[8];
+    constexpr float LOG2E = 1.4426950408889634f;
+    // (the stages are pure arithmetic: nothing but their operands orders them, and left alone the instruction selector gathers
+    // a pair's stages in front of their first use - the empty asm statements tie each stage's results to its place in the stream)
+    auto hold2 = [&](float& a, float& b) __attribute__((always_inline)) { asm volatile("" : "+v"(a), "+v"(b)); };
+    auto micro = [&](auto mc) __attribute__((always_inline)) {
+      constexpr int m = decltype(mc)::value, q = m >> 3, st = m & 7, rt = q >> 2, ct = (q >> 1) & 1, i0 = 2 * (q & 1);
       if constexpr ((BB_DIAG & 4) != 0) {
-        mh[rt] = __builtin_bit_cast(f16x8, u32x4{__float_as_uint(acc1[rt][0][0]), __float_as_uint(acc1[rt][0][1]), __float_as_uint(acc1[rt][1][0]), __float_as_uint(acc1[rt][1][1])});
-        ml[rt] = __builtin_bit_cast(f16x8, u32x4{__float_as_uint(acx1[rt][0][0]), __float_as_uint(acx1[rt][0][1]), __float_as_uint(acx1[rt][1][0]), __float_as_uint(acx1[rt][1][1])});
-        continue;
+        if constexpr (st == 7) {
+          ehp[q] = __float_as_uint(acc1[rt][ct][i0]);
+          elp[q] = __float_as_uint(acx1[rt][ct][i0 + 1]);
+        }
+      } else if constexpr (st == 0) {
+        asm volatile("" : "+v"(acc1[rt][ct]), "+v"(acx1[rt][ct]));
+        ev[q][0] = fmaf(acx1[rt][ct][i0], xw1, acc1[rt][ct][i0] * inv1);
+        ev[q][1] = fmaf(acx1[rt][ct][i0 + 1], xw1, acc1[rt][ct][i0 + 1] * inv1);
+        hold2(ev[q][0], ev[q][1]);
+      } else if constexpr (st == 1) {
+        ee[q][0] = ev[q][0] * LOG2E;
+        ee[q][1] = ev[q][1] * LOG2E;
+        hold2(ee[q][0], ee[q][1]);
+      } else if constexpr (st == 2) {
+        ee[q][0] = __builtin_amdgcn_exp2f(ee[q][0]);
+        ee[q][1] = __builtin_amdgcn_exp2f(ee[q][1]);
+        hold2(ee[q][0], ee[q][1]);
+      } else if constexpr (st == 3) {
+        ev[q][0] = ev[q][0] > 0.f ? ev[q][0] : ee[q][0] - 1.0f;
+        hold2(ev[q][0], ee[q][1]);
+      } else if constexpr (st == 4) {
+        ev[q][1] = ev[q][1] > 0.f ? ev[q][1] : ee[q][1] - 1.0f;
+        hold2(ev[q][0], ev[q][1]);
+      } else if constexpr (st == 5) {
+        ev[q][0] *= sC;
+        ev[q][1] *= sC;
+        ehp[q] = pack_f16(ev[q][0], ev[q][1]);
+        hold2(ev[q][0], ev[q][1]);
+        asm volatile("" : "+v"(ehp[q]));
+      } else if constexpr (st == 6) {
+        const f16x2 hh = __builtin_bit_cast(f16x2, ehp[q]);
+        ee[q][0] = (float)hh.x;
+        ee[q][1] = (float)hh.y;
+        hold2(ee[q][0], ee[q][1]);
+      } else {
+        elp[q] = pack_f16((ev[q][0] - ee[q][0]) * 2048.f, (ev[q][1] - ee[q][1]) * 2048.f);
+        asm volatile("" : "+v"(elp[q]));
       }
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct) {
-        v[ct].x = act_ct<1>(fmaf(acx1[rt][ct][0], xw1, acc1[rt][ct][0] * inv1), 0.f) * sC;
-        v[ct].y = act_ct<1>(fmaf(acx1[rt][ct][1], xw1, acc1[rt][ct][1] * inv1), 0.f) * sC;
-        v[ct].z = act_ct<1>(fmaf(acx1[rt][ct][2], xw1, acc1[rt][ct][2] * inv1), 0.f) * sC;
-        v[ct].w = act_ct<1>(fmaf(acx1[rt][ct][3], xw1, acc1[rt][ct][3] * inv1), 0.f) * sC;
-      }
-      u32x2 h0, l0, h1, l1;
-      split4h(v[0], h0, l0);
-      split4h(v[1], h1, l1);
-      const u32x4 hh = {h0.x, h0.y, h1.x, h1.y}, ll = {l0.x, l0.y, l1.x, l1.y};
-      mh[rt] = *reinterpret_cast<const f16x8*>(&hh);
-      ml[rt] = *reinterpret_cast<const f16x8*>(&ll);
-    }
-    BB_PIN;
+      BB_PIN;
+    };
+    constexpr int MS = 64 / (8 * G2) > 0 ? 64 / (8 * G2) : 1;       // micro-steps per gap (8 gaps per group)
+    static_assert(MS * 8 * G2 >= 64, "every micro-step has a gap");
+
     z_req(std::integral_constant<int, ZG1>{});
-    if constexpr (stamp_on) asm volatile("s_nop 0" ::"v"(mh[0]), "v"(mh[1]), "v"(ml[0]), "v"(ml[1]));
     stamp(4);
 
-    // ---- GEMM 2: this chunk is k-step (h, j) of [32 rows] x [N2]; two column tiles per group
-    bb_static_for<G2>([&](auto nc) __attribute__((always_inline)) {
-      constexpr int np = decltype(nc)::value;
-      f16x8(&cur)[4] = f[(G1 + np) & 1];
-      f16x8(&nxt)[4] = f[(G1 + np + 1) & 1];
-      auto mfma = [&](auto ic, f16x8& w) __attribute__((always_inline)) {
-        constexpr int i = decltype(ic)::value, rt = i & 1, c = (i >> 1) & 1, ph = i >> 2, nt = 2 * np + c;
-        if constexpr ((BB_DIAG & 8) != 0) {
-          asm volatile("" ::"v"(w));
-        } else if constexpr (ph == 0) {
-          acc2[rt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w, mh[rt], acc2[rt][nt], 0, 0, 0);
-        } else if constexpr (ph == 1) {
-          acx2[rt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w, mh[rt], acx2[rt][nt], 0, 0, 0);
-        } else {
-          acx2[rt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w, ml[rt], acx2[rt][nt], 0, 0, 0);
-        }
-      };
-      auto rdn = [&](auto kc) __attribute__((always_inline)) { rd2(nxt, std::integral_constant<int, (np + 1 < G2 ? np + 1 : 0)>{}, kc); };
-      // (k-steps ZG1+1 .. KT-1 behind every ZS-th group, the last one early enough to land before its use)
-      constexpr int ZREM = KT - ZG1 - 1 > 0 ? KT - ZG1 - 1 : 0, ZS = ZREM > 0 ? (G2 / ZREM > 0 ? G2 / ZREM : 1) : 1;
-      auto tail = [&]() __attribute__((always_inline)) {
-        if constexpr (ZREM > 0 && np % ZS == 0 && np / ZS < ZREM) z_req(std::integral_constant<int, ZG1 + 1 + np / ZS>{});
-      };
-      if constexpr (np + 1 < G2) group(cur, std::true_type{}, mfma, rdn, tail);
-      else group(cur, std::false_type{}, mfma, rdn, tail);
-    });
+    // ---- GEMM 2 of the PREVIOUS chunk (its k-step of [32 rows] x [N2]; two column tiles per group), this chunk's arithmetic in its gaps
+    // (k-steps ZG1+1 .. KT-1 of the next head's Z behind every ZS-th group, the last one early enough to land before its use)
+    constexpr int ZREM = KT - ZG1 - 1 > 0 ? KT - ZG1 - 1 : 0, ZS = ZREM > 0 ? (G2 / ZREM > 0 ? G2 / ZREM : 1) : 1;
+    gemm2(sa_prev, f,
+          [&](auto nc, auto kc) __attribute__((always_inline)) {
+            bb_static_for<MS>([&](auto uc) __attribute__((always_inline)) {
+              constexpr int m = (decltype(nc)::value * 8 + decltype(kc)::value) * MS + decltype(uc)::value;
+              if constexpr (m < 64) micro(std::integral_constant<int, m>{});
+            });
+          },
+          [&](auto nc) __attribute__((always_inline)) {
+            constexpr int np = decltype(nc)::value;
+            if constexpr (ZREM > 0 && np % ZS == 0 && np / ZS < ZREM) z_req(std::integral_constant<int, ZG1 + 1 + np / ZS>{});
+          });
+    // the intermediate of this chunk: GEMM 2's operand in the next step
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      mh[rt] = __builtin_bit_cast(f16x8, u32x4{ehp[4 * rt], ehp[4 * rt + 1], ehp[4 * rt + 2], ehp[4 * rt + 3]});
+      ml[rt] = __builtin_bit_cast(f16x8, u32x4{elp[4 * rt], elp[4 * rt + 1], elp[4 * rt + 2], elp[4 * rt + 3]});
+    }
+    BB_PIN;
   };
 
   // (two step bodies only - with more variants in the loop nest the allocator spilled GEMM 2's 256 accumulators; nj >= 2)
@@ -433,7 +513,21 @@ __global__ __launch_bounds__(256, 1) void proj_fuse_kernel(const B2BArgs G) {
     step(s, h, nj - 1, h_next, false, std::true_type{});
     ++s;
   }
-  bb_wait_vm<0>();        // the idle slot's re-request: landed before the LDS is released
+  // ---- drain: GEMM 2 of the last chunk (its W2 part was requested by the last step into that step's slot)
+  {
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __builtin_amdgcn_s_barrier();
+    BB_PIN;
+    const uint32_t sap = sa0 + ((s - 1) & 1) * SLOT;
+    f16x8 fd[2][4];
+    rd2(sap, fd[G1 & 1], c0, c0);
+    rd2(sap, fd[G1 & 1], c0, c1);
+    rd2(sap, fd[G1 & 1], c0, c2);
+    rd2(sap, fd[G1 & 1], c0, c3);
+    BB_PIN;
+    gemm2(sap, fd, [&](auto, auto) __attribute__((always_inline)) {}, [&](auto) __attribute__((always_inline)) {});
+  }
+  bb_wait_vm<0>();        // the last step's re-requests: landed before the LDS is released
 
   if constexpr (stamp_on) {
     asm volatile("s_nop 0" ::"v"(acc2[0][0]), "v"(acx2[1][NT2 - 1]));

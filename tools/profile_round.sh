@@ -6,7 +6,7 @@
 # PMC passes never combine with sys/hip/hsa tracing (the pool refuses that); the profiled program is python3 itself.
 set -u
 ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
-OUT="$ROOT/gpurun_out/${1:-r04/prof}"
+OUT="$ROOT/gpurun_out/${1:-r05/prof}"
 STAGE="${2:-all}"       # all | bench | gemm | att2 | train | sampler: the stages as separate gpurun calls
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
