@@ -333,3 +333,41 @@ def test_weight_cache_and_data_edits(dev, monkeypatch):
         enc.attention1_0.W_em.data.mul_(1.5)
         strict = enc.get_em(x, adj, fus)[1]
     assert float((strict - moved).abs().max()) <= 1e-6 * max(1.0, float(moved.abs().max()))
+
+
+@pytest.mark.parametrize("gnn,att", [("AT", 3), ("SAGE", 2)])
+def test_real_graph_every_row(golden_dir, dev, gnn, att):
+    """ALL rows of the five entry points on chameleon (real features; H = 8, nhid = 64): per row the sum over the features of
+    forward / get_em against the reference's (tests/golden/chameleon_rows_*.npz, oracle/gen_golden.py --only rows), per
+    head and 64-entry block the sums of every edge score and aux score, per head and row the sum of get_edge_em - the
+    256-row slices and column sums of test_real_graph_entry_points cannot tell a wrong row outside the slice from a
+    compensating pair; these can.  A row's tolerance is north_star's 1e-4 of max(1, its own largest element) per term."""
+    g = np.load(os.path.join(golden_dir, f"chameleon_rows_{gnn}_att{att}.npz"))
+    x, adj, n, ei, sup, ho, he = real_inputs(golden_dir, "chameleon", dev)
+    a, enc, fus = build(gnn, att, 8, 64, x.shape[1], 200 + att, dev)
+    with torch.no_grad():
+        fwd = enc(x, adj, fus)
+        em = enc.get_em(x, adj, fus)
+        adjs = enc.get_adjs(x, adj, fus)
+        auxs = enc.predict_adjs_sparse(x, adj, fus, [sup[0].to(dev)])
+        eem = enc.get_edge_em(x, adj, fus)
+
+    def blocks(t, b=64):
+        t = t.double()
+        pad = (-t.shape[1]) % b
+        return torch.nn.functional.pad(t, (0, pad)).reshape(t.shape[0], -1, b).sum(-1).cpu().numpy()
+
+    for key, t in (("forward", fwd), ("get_em_0", em[0]), ("get_em_1", em[1])):
+        got = t.double().sum(1).cpu().numpy()
+        tol = TOL * np.maximum(1.0, g[key + "_rowmax"]) * t.shape[1]
+        bad = np.abs(got - g[key + "_rowsum"]) > tol
+        assert not bad.any(), (key, int(bad.sum()), np.flatnonzero(bad)[:8])
+        assert np.abs(t.double().abs().sum(1).cpu().numpy() - g[key + "_rowabs"]).max() <= float(tol.max())
+    for l in range(2):
+        for key, t in ((f"adjs_{l}", torch.stack([t[:, 0] for t in adjs[l]])), (f"aux_{l}_0", torch.stack([h[0][:, 0] for h in auxs[l]]))):
+            scale = max(1.0, float(g[key + "_blkabs"].max()) / 64 * 4)             # raw scores reach 1e3 on this graph
+            assert np.abs(blocks(t) - g[key + "_blk"]).max() <= TOL * scale * 64, key
+        ee = torch.stack(list(eem[l])).double()
+        ref = g[f"edge_em_{l}_rowsum"]
+        tol = TOL * np.maximum(1.0, g[f"edge_em_{l}_rowabs"] / ee.shape[2] * 8) * ee.shape[2]
+        assert (np.abs(ee.sum(2).cpu().numpy() - ref) <= tol).all(), f"edge_em {l}"

@@ -117,7 +117,8 @@ def test_parameters_after_three_epochs_match_the_reference(golden_dir, dev, gnn,
     assert checked == len(g.files) - 6          # losses, cls_logs, cls_test and the three index sets
 
 
-@pytest.mark.parametrize("name,gnn,att", [("cora", "AT", 3), ("cora", "SAGE", 1), ("chameleon", "AT", 3)])
+@pytest.mark.parametrize("name,gnn,att", [("cora", "AT", 3), ("cora", "SAGE", 1), ("chameleon", "AT", 3), ("chameleon", "SAGE", 1),
+                                          ("chameleon", "SAGE", 3)])
 def test_real_graph_parameters_after_two_epochs_match_the_reference(golden_dir, dev, name, gnn, att):
     """The same pin at the real configurations (BASELINE configs[0] / [1]): Cora (bundled adjacency, seeded surrogate
     features) and chameleon (real features), H = 8, nhid = 64, two epochs of CLS -> SupEdge -> DisEdge -> DifHead with the
@@ -132,8 +133,9 @@ def test_real_graph_parameters_after_two_epochs_match_the_reference(golden_dir, 
     1e-8..3e-5), the number of outlying elements to the reference's own count (x4, or 2.5 % of the tensor), no element
     further than the 8 steps x lr it can move at all, losses to 2e-4 + 4 x their recorded sensitivity.  A wrong step
     order, shared moments, a missing optimiser or a wrong lr moves EVERY element by 1e-3..1e-2.
-    (SAGE on chameleon - N(0,1) weights on features of magnitude 9e2, losses ~5e2 - amplifies the same noise into 1 % loss
-    differences after one epoch and is not pinned; Cora carries SAGE.)"""
+    Round 5: SAGE on chameleon too (N(0,1) weights on features of magnitude 9e2, losses ~5e2: the reference's own 2-ulp
+    perturbation moves single parameters by up to 4.5e-2 and the logged losses by up to 9e-2 - its recorded sensitivity is
+    the yardstick, as for the other graphs)."""
     import random
     from edgedisentangle_ssl_amd import pretrainer, utils
     from edgedisentangle_ssl_amd.trainer import ClsTrainer
@@ -191,10 +193,16 @@ def test_real_graph_parameters_after_two_epochs_match_the_reference(golden_dir, 
         d = (head - torch.from_numpy(np.asarray(g[key], dtype=np.float64))).abs()
         assert torch.isfinite(pc).all(), key
         # (chameleon: the score parameters sit behind a saturated sigmoid - raw scores ~1e3 - and their whole gradient is noise)
-        assert float(d.median()) <= (4e-4 if name == "chameleon" else 1e-4), (key, "median", float(d.median()))
+        # (SAGE on chameleon: the reference's own median movement under the 2-ulp perturbation is recorded, `#med`.  Another
+        # fp32 evaluation order differs from the reference's by ~1e-6 relative, several times the probe's perturbation -
+        # measured here: medians up to 9.5x and outlier counts up to 4.1x the reference's own; held to 16x / 8x.  What pins
+        # this combination is above: the first CLS log to 2e-5 and every loss to its recorded sensitivity.)
+        loose = key + "#med" in g.files
+        med_ref = float(g[key + "#med"]) if loose else 0.0
+        assert float(d.median()) <= max(4e-4 if name == "chameleon" else 1e-4, 16 * med_ref), (key, "median", float(d.median()), med_ref)
         assert float(d.max()) <= 8 * 0.01 * 1.05, (key, "max", float(d.max()))
         n_out = int((d > PTOL).sum())
-        assert n_out <= max(4 * int(g[key + "#nflip"]), d.numel() // 40, 8), (key, "outliers", n_out, int(g[key + "#nflip"]), d.numel())
+        assert n_out <= max((8 if loose else 4) * int(g[key + "#nflip"]), d.numel() // 40, 8), (key, "outliers", n_out, int(g[key + "#nflip"]), d.numel())
         checked += 1
 
     for k, p in enc.state_dict().items():
@@ -209,4 +217,5 @@ def test_real_graph_parameters_after_two_epochs_match_the_reference(golden_dir, 
     for nm in ("fuse1", "fuse2", "classifier"):
         for k, p in getattr(ct, nm).state_dict().items():
             same(p, f"cls.{nm}.{k}")
-    assert 5 * checked == len(g.files) - 7          # losses, cls_logs, their sensitivities and the three index sets
+    per = 6 if any(k.endswith("#med") for k in g.files) else 5
+    assert per * checked == len(g.files) - 7        # losses, cls_logs, their sensitivities and the three index sets
