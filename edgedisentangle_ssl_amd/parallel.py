@@ -194,6 +194,8 @@ class GatherAdjoint:
 
 
 ADJOINT_EARLY_STARTS = 0        # how many adjoints were put on the links by their producer (tests read this)
+ADJOINT_EARLY_TAKEN = 0         # ... and how many of those _AllGatherRows.backward picked up (tests: started == taken)
+_ADJOINT_OPEN = []              # early adjoints nobody has collected yet: an orphan is waited for before the plain path runs
 
 
 def start_adjoint(x_all, g):
@@ -206,6 +208,7 @@ def start_adjoint(x_all, g):
     if info is None or g is None or tuple(g.shape) != tuple(x_all.shape):
         return False
     g._disgat_adjoint = GatherAdjoint(g, *info)
+    _ADJOINT_OPEN.append(g._disgat_adjoint)
     ADJOINT_EARLY_STARTS += 1
     return True
 
@@ -224,10 +227,18 @@ class _AllGatherRows(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        global ADJOINT_EARLY_TAKEN
         early = getattr(g, "_disgat_adjoint", None)
         if early is not None and early.src_version == g._version:      # already on the links (start_adjoint)
             g._disgat_adjoint = None
+            if early in _ADJOINT_OPEN:
+                _ADJOINT_OPEN.remove(early)
+            ADJOINT_EARLY_TAKEN += 1
             return early.result(), None, None, None, None
+        # the gradient is not the tensor the producer tagged (autograd summed several contributions or re-wrapped it): an early
+        # reduce-scatter may be in flight for a PART of it - wait for it (its result is dropped) before the whole sum goes out
+        while _ADJOINT_OPEN:
+            _ADJOINT_OPEN.pop().result()
         return GatherAdjoint(g, ctx.counts, ctx.group).result(), None, None, None, None
 
 

@@ -27,7 +27,10 @@ _I64_MAX = (1 << 63) - 1
 # The trainers' eager train_step()s (pretrainer.*.sample_train) take their lists at FIXED capacity (sample_padded: the
 # valid length stays on the device, the tail is padding the loss kernels skip) instead of exact length: every buffer sized by
 # the list - scores, sign records (17 GB at 1M nodes), gradients - then has the same size every step and comes back from the
-# caching allocator, and the step has no host read at all.  With exact lengths the sizes wander by a few MB from step to step
+# caching allocator.  (The eager step's BACKWARD still reads two numbers back while it builds its segment tables -
+# ops_bwd._segments: sortedness, item count; only captured steps, whose lists carry `_disgat_static`, take the read-free
+# ops_bwd._segments_static - and the padding tail, 8 sigma + overlap, is scored and segmented like real pairs under the last
+# key.)  With exact lengths the sizes wander by a few MB from step to step
 # and a step occasionally pays for fresh device allocations of tens of GB (a bench.py run read 1 392 ms for a 1 024 ms step).
 PADDED_LISTS = True
 

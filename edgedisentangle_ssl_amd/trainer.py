@@ -87,6 +87,12 @@ class ClsTrainer(Trainer):
         hit = self.__dict__.get("_cls_codes")
         if hit is not None and hit[0] is labels and hit[1] is graph and hit[2] == labels._version:
             return hit[3]
+        # once per (labels, graph), outside any captured step: the kernel indexes a row's logits with its label (F.nll_loss
+        # raises on an out-of-range target; a label >= 65536 would also spill into the split bit of the code)
+        n_cls = int(self.classifier.model[-1].out_features) if hasattr(self.classifier, "model") else 65535
+        lo, hi = (int(v) for v in torch.aminmax(labels)) if labels.numel() else (0, 0)
+        if lo < 0 or hi >= min(n_cls, 65536):
+            raise ValueError(f"class labels must lie in [0, {min(n_cls, 65536)}): got [{lo}, {hi}]")
         code = torch.full((graph.n,), -1, dtype=torch.int32, device=labels.device)
         for split, idx in ((1, self.idx_val), (0, self.idx_train)):
             loc, glob, _ = self._local(idx, graph)

@@ -201,6 +201,7 @@ def _train_worker(rank, world, port, q, golden_dir):
         # weight-gradient GEMM (ops_bwd.layer_backward_u -> parallel.start_adjoint): once per SSL step (layer 2; the features
         # that enter layer 1 need no gradient, so nothing travels back there)
         assert parallel.ADJOINT_EARLY_STARTS == 3, parallel.ADJOINT_EARLY_STARTS
+        assert parallel.ADJOINT_EARLY_TAKEN == 3 and not parallel._ADJOINT_OPEN
         import random
         random.seed(7)                                      # the node split is drawn from `random`: same on every rank
         cls_t = ClsTrainer(a, enc, lab, 1.0)

@@ -228,6 +228,7 @@ def _worker_many(rank, world, port, q):
         co = torch.sin(torch.arange(n * 8, dtype=torch.float32).view(n, 8)) * (rank + 1)
         (Consumer.apply(xa, we) * co).sum().backward()
         assert parallel.ADJOINT_EARLY_STARTS == before + 1
+        assert parallel.ADJOINT_EARLY_TAKEN == parallel.ADJOINT_EARLY_STARTS and not parallel._ADJOINT_OPEN      # started == picked up
         co_tot = torch.sin(torch.arange(n * 8, dtype=torch.float32).view(n, 8)) * tot
         assert torch.allclose(xe.grad, (co_tot @ we.detach().t())[lo:lo + dg.n], atol=1e-4 * world)
         assert torch.allclose(we.grad, x.t() @ co, atol=1e-3)
