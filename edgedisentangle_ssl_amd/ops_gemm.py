@@ -260,6 +260,41 @@ def linear_planes(ap, w_rm, n, bias=None, init=None, act=ACT_NONE, slope=0.01, w
     return out, (None if oh is None else Planes(oh, ol, out_bound))
 
 
+_KPAD = {}          # (data_ptr, version, shape) -> (tensor kept alive, zero-padded copy): padded copies of constant operands
+
+
+def _pad_to_tiles(a, w, k, n):
+    """A large 2-D product whose K is not a multiple of 32 or whose N is off the kernels' column granule (raw bag-of-words
+    features: Cora 1 433, cora_full 8 710 columns; /root/reference/main.py:108 takes the width from the data file) as a
+    product the f16x3 kernels tile: K zero-padded to 32 - the padded copy of an operand that needs no gradient (the feature
+    matrix: a run constant) is kept and reused while the tensor is unchanged - and the weight's columns zero-padded to the
+    granule.  hipBLASLt's fp32 GEMM, where such shapes went, runs at the vector rate on CDNA4.  Returns (a', w', Kp, Np) or
+    None when the shape is small (launch-bound: the library's one launch is the cheaper route) or already tiles."""
+    if mode() != "f16x3" or a.dim() != 2 or not a.is_cuda or a.dtype != torch.float32 or os.environ.get("DISGAT_PAD_SHAPES", "1") == "0":
+        return None
+    m = a.shape[0]
+    kp = -(-k // 32) * 32
+    gran = 32 if kp in (64, 128, 256) else 128
+    np_ = -(-n // gran) * gran
+    if (kp == k and np_ == n) or m < 8192 or 2.0 * m * kp * np_ < 1e9 or np_ > 4 * n:
+        return None
+    if kp != k or a.stride(1) != 1 or a.stride(0) % 4 or a.data_ptr() % 16:
+        key = (a.data_ptr(), a._version, tuple(a.shape), tuple(a.stride()))
+        hit = _KPAD.get(key) if not a.requires_grad else None
+        if hit is None:
+            ap = F.pad(a.detach(), (0, kp - k))
+            if not a.requires_grad:
+                if len(_KPAD) >= 4:
+                    _KPAD.pop(next(iter(_KPAD)))
+                _KPAD[key] = (a, ap)
+        else:
+            ap = hit[1]
+    else:
+        ap = a
+    wp = F.pad(w.detach(), (0, np_ - n, 0, kp - k)) if (kp != k or np_ != n) else w
+    return ap, wp, kp, np_
+
+
 def _forward(a, w, bias, init, act, slope, a_amax=None, w_split=None, out=None):
     """out: optional preallocated 2-D result (row-contiguous view, e.g. a row block of a larger table) to write into."""
     batched = a.dim() == 3
@@ -268,6 +303,14 @@ def _forward(a, w, bias, init, act, slope, a_amax=None, w_split=None, out=None):
         n = w.shape[2]
     else:
         hb, (m, k), n = 1, a.shape, w.shape[1]
+        if out is None and not _kernel_ok(a, k, n):
+            padded = _pad_to_tiles(a, w, k, n)
+            if padded is not None:
+                ap, wp, kp, np_ = padded
+                bp = None if bias is None else F.pad(bias, (0, np_ - n))
+                ip = None if init is None else F.pad(init.expand(m, n), (0, np_ - n))
+                res = _forward(ap, wp, bp, ip, act, slope, a_amax if kp == k else None, None)
+                return res if np_ == n else res[:, :n].contiguous()
     out_arg = out
     if out_arg is not None and (tuple(out_arg.shape) != (m, hb * n) or out_arg.stride(-1) != 1 or out_arg.dtype != torch.float32):
         raise RuntimeError("ops_gemm: `out` must be a float32 [M, N] view with unit inner stride")
