@@ -29,6 +29,11 @@
 // GEMMs) runs UNDER matrix work: GEMM 2 is one chunk behind - step s is [GEMM 1 (s)] [GEMM 2 (s-1) with the arithmetic of
 // chunk s, two or three instructions at a time, in its MFMA gaps], the intermediate of chunk s-1 waiting in 16 registers.
 // Step 0 runs GEMM 2 on a zero intermediate; GEMM 2 of the last chunk follows the loop.
+// Measured and dropped (profiles/r05/b2b_*_stamps.log, tools/b2b_ablate.sh): the arithmetic as 192 single instructions, two per
+// MFMA gap - they cost their full ~3.6 cycles each, nothing hides under a 16-cycle MFMA in this one-wave-per-SIMD stream
+// (6.03 ms against 5.88); the whole kernel on v_mfma_f32_32x32x16_f16 (one 32 x 32 tile per chunk, 6 MFMAs per group, four
+// instructions per 32-cycle gap) - about half of the arithmetic hides there, but the accumulator seed, the dependent MFMA
+// pairs on the single tile and the paced Z requests cost more than that buys: 6.88 ms.
 // Arithmetic per chunk and wave: 96 + 96 MFMAs (16x16x32 f16), 64 ds_read_b128, 16 DMA pieces, ~150 vector instructions.
 // HBM: the Z planes once (8.2 GB) + 1 GB of output; the head buffer's 16.4 GB round trip is gone.
 #include <stdlib.h>
@@ -240,43 +245,39 @@ __global__ __launch_bounds__(256, 1) void proj_fuse_kernel(const B2BArgs G) {
   // A group: 12 MFMAs on fragments cur[0..3] - MFMA i uses cur[0], cur[0], cur[1], cur[1] (hi x hi), cur[2], cur[2], cur[3],
   // cur[3] (lo x hi), cur[0], cur[0], cur[1], cur[1] (hi x lo) - with the NEXT group's four reads in the first four gaps
   // and the waits counted on what is outstanding in issue order: [c0 c1 c2 c3] at entry, then n0, n1 behind M0, M1, ...
-  //   W(c0) M0 R(n0) g M1 R(n1) g W(c1) M2 R(n2) g M3 R(n3) g W(c2) M4 g M5 g W(c3) M6 g M7 g M8 [tail] g M9 g M10 g M11 g
+  //   W(c0) M0 R(n0) M1 R(n1) W(c1) M2 R(n2) M3 R(n3) W(c2) M4 g M5 g W(c3) M6 g M7 g M8 [tail] g M9 g M10 g M11 g
   // (g: a gap the caller may fill - GEMM 2 puts the ELU / split arithmetic there)
   auto group = [&](f16x8(&cur)[4], auto has_next_c, auto&& mfma, auto&& rdn, auto&& tail, auto&& gap) __attribute__((always_inline)) {
     constexpr bool HN = decltype(has_next_c)::value;
     bb_lw<3>(cur[0]);
     mfma(c0, cur[0]); BB_PIN;
     if constexpr (HN) { rdn(c0); BB_PIN; }
-    gap(c0);
     mfma(c1, cur[0]); BB_PIN;
     if constexpr (HN) { rdn(c1); BB_PIN; }
-    gap(c1);
     bb_lw<HN ? 4 : 2>(cur[1]);
     mfma(c2, cur[1]); BB_PIN;
     if constexpr (HN) { rdn(c2); BB_PIN; }
-    gap(c2);
     mfma(c3, cur[1]); BB_PIN;
     if constexpr (HN) { rdn(c3); BB_PIN; }
-    gap(c3);
     bb_lw<HN ? 5 : 1>(cur[2]);
     mfma(std::integral_constant<int, 4>{}, cur[2]); BB_PIN;
-    gap(std::integral_constant<int, 4>{});
+    gap(c0);
     mfma(std::integral_constant<int, 5>{}, cur[2]); BB_PIN;
-    gap(std::integral_constant<int, 5>{});
+    gap(c1);
     bb_lw<HN ? 4 : 0>(cur[3]);
     mfma(std::integral_constant<int, 6>{}, cur[3]); BB_PIN;
-    gap(std::integral_constant<int, 6>{});
+    gap(c2);
     mfma(std::integral_constant<int, 7>{}, cur[3]); BB_PIN;
-    gap(std::integral_constant<int, 7>{});
+    gap(c3);
     mfma(std::integral_constant<int, 8>{}, cur[0]); BB_PIN;
     tail();
-    gap(std::integral_constant<int, 8>{});
+    gap(std::integral_constant<int, 4>{});
     mfma(std::integral_constant<int, 9>{}, cur[0]); BB_PIN;
-    gap(std::integral_constant<int, 9>{});
+    gap(std::integral_constant<int, 5>{});
     mfma(std::integral_constant<int, 10>{}, cur[1]); BB_PIN;
-    gap(std::integral_constant<int, 10>{});
+    gap(std::integral_constant<int, 6>{});
     mfma(std::integral_constant<int, 11>{}, cur[1]); BB_PIN;
-    gap(std::integral_constant<int, 11>{});
+    gap(std::integral_constant<int, 7>{});
   };
   auto no_gap = [&](auto) __attribute__((always_inline)) {};
 
@@ -430,89 +431,57 @@ __global__ __launch_bounds__(256, 1) void proj_fuse_kernel(const B2BArgs G) {
     // column 4 q + e of tile 0 for e < 4, of tile 1 for e >= 4 - the order W2's rows were permuted to.
     bb_fence8(acc1, acx1, true);
     stamp(3);
-    // 192 single-instruction micro-ops: per value (16 of them) v = acc inv, v += acx xw, e = v log2(e), e = exp2(e), e -= 1,
-    // e = min(e, 0), v = max(v, e) [= v > 0 ? v : exp(v) - 1], v *= s_C; per pair of values h = pack(v0, v1), the two
-    // halves back as fp32, the two residuals, their 2^11 scaling, l = pack.  Two per MFMA gap is what the matrix pipe hides
-    // (it holds the wave's vector issue for 8 of an MFMA's 16 cycles); the pair stages of pair q-1 sit between the value
-    // stages of pair q, so no micro-op reads the result of the one in front of it.
-    float ev[16], ee[16];
+    float ev[8][2], ee[8][2];
     uint32_t ehp[8], elp[8];
     constexpr float LOG2E = 1.4426950408889634f;
-    // (pure arithmetic: nothing but their operands orders these, and left alone the instruction selector gathers a value's
-    // stages in front of their first use - the empty asm statements tie each result to its place in the stream)
-    auto hold = [&](float& x) __attribute__((always_inline)) { asm volatile("" : "+v"(x)); };
-    auto vstage = [&](auto vc, auto sc) __attribute__((always_inline)) {
-      constexpr int v = decltype(vc)::value, st = decltype(sc)::value, q = v >> 1, rt = q >> 2, ct = (q >> 1) & 1, i = 2 * (q & 1) + (v & 1);
-      if constexpr (st == 0) {
-        asm volatile("" : "+v"(acc1[rt][ct]), "+v"(acx1[rt][ct]));
-        ev[v] = acc1[rt][ct][i] * inv1;
-      } else if constexpr (st == 1) {
-        ev[v] = fmaf(acx1[rt][ct][i], xw1, ev[v]);
-      } else if constexpr (st == 2) {
-        ee[v] = ev[v] * LOG2E;
-      } else if constexpr (st == 3) {
-        ee[v] = __builtin_amdgcn_exp2f(ee[v]);
-      } else if constexpr (st == 4) {
-        ee[v] = ee[v] - 1.0f;
-      } else if constexpr (st == 5) {
-        ee[v] = fminf(ee[v], 0.f);
-      } else if constexpr (st == 6) {
-        ev[v] = fmaxf(ev[v], ee[v]);
-      } else {
-        ev[v] = ev[v] * sC;
-      }
-      if constexpr (st >= 2 && st <= 5) hold(ee[v]);
-      else hold(ev[v]);
-    };
-    auto pstage = [&](auto qc, auto sc) __attribute__((always_inline)) {
-      constexpr int q = decltype(qc)::value, st = decltype(sc)::value, v0 = 2 * q, v1 = 2 * q + 1;
-      if constexpr (st == 0) {
-        ehp[q] = pack_f16(ev[v0], ev[v1]);
-        asm volatile("" : "+v"(ehp[q]));
-      } else if constexpr (st == 1) {
-        ee[v0] = (float)__builtin_bit_cast(f16x2, ehp[q]).x;
-        hold(ee[v0]);
-      } else if constexpr (st == 2) {
-        ee[v1] = (float)__builtin_bit_cast(f16x2, ehp[q]).y;
-        hold(ee[v1]);
-      } else if constexpr (st == 3) {
-        ev[v0] = ev[v0] - ee[v0];
-        hold(ev[v0]);
-      } else if constexpr (st == 4) {
-        ev[v1] = ev[v1] - ee[v1];
-        hold(ev[v1]);
-      } else if constexpr (st == 5) {
-        ev[v0] = ev[v0] * 2048.f;
-        hold(ev[v0]);
-      } else if constexpr (st == 6) {
-        ev[v1] = ev[v1] * 2048.f;
-        hold(ev[v1]);
-      } else {
-        elp[q] = pack_f16(ev[v0], ev[v1]);
-        asm volatile("" : "+v"(elp[q]));
-      }
-    };
-    // micro-op o of 192: 16 value stages of pair 0; then per pair q = 1 .. 7 the triples (stage s of value 2 q, of value
-    // 2 q + 1, pair stage s of pair q - 1), s = 0 .. 7; then the 8 pair stages of pair 7
-    auto micro = [&](auto oc) __attribute__((always_inline)) {
-      constexpr int o = decltype(oc)::value;
+    // (the stages are pure arithmetic: nothing but their operands orders them, and left alone the instruction selector gathers
+    // a pair's stages in front of their first use - the empty asm statements tie each stage's results to its place in the stream)
+    auto hold2 = [&](float& a, float& b) __attribute__((always_inline)) { asm volatile("" : "+v"(a), "+v"(b)); };
+    auto micro = [&](auto mc) __attribute__((always_inline)) {
+      constexpr int m = decltype(mc)::value, q = m >> 3, st = m & 7, rt = q >> 2, ct = (q >> 1) & 1, i0 = 2 * (q & 1);
       if constexpr ((BB_DIAG & 4) != 0) {
-        if constexpr (o < 8) {
-          ehp[o] = __float_as_uint(acc1[o >> 2][(o >> 1) & 1][2 * (o & 1)]);
-          elp[o] = __float_as_uint(acx1[o >> 2][(o >> 1) & 1][2 * (o & 1) + 1]);
+        if constexpr (st == 7) {
+          ehp[q] = __float_as_uint(acc1[rt][ct][i0]);
+          elp[q] = __float_as_uint(acx1[rt][ct][i0 + 1]);
         }
-      } else if constexpr (o < 16) {
-        vstage(std::integral_constant<int, (o & 1)>{}, std::integral_constant<int, (o >> 1)>{});
-      } else if constexpr (o < 16 + 7 * 24) {
-        constexpr int q = 1 + (o - 16) / 24, pos = (o - 16) % 24, s3 = pos / 3, r = pos % 3;
-        if constexpr (r < 2) vstage(std::integral_constant<int, 2 * q + r>{}, std::integral_constant<int, s3>{});
-        else pstage(std::integral_constant<int, q - 1>{}, std::integral_constant<int, s3>{});
-      } else if constexpr (o < 192) {
-        pstage(std::integral_constant<int, 7>{}, std::integral_constant<int, o - 16 - 7 * 24>{});
+      } else if constexpr (st == 0) {
+        asm volatile("" : "+v"(acc1[rt][ct]), "+v"(acx1[rt][ct]));
+        ev[q][0] = fmaf(acx1[rt][ct][i0], xw1, acc1[rt][ct][i0] * inv1);
+        ev[q][1] = fmaf(acx1[rt][ct][i0 + 1], xw1, acc1[rt][ct][i0 + 1] * inv1);
+        hold2(ev[q][0], ev[q][1]);
+      } else if constexpr (st == 1) {
+        ee[q][0] = ev[q][0] * LOG2E;
+        ee[q][1] = ev[q][1] * LOG2E;
+        hold2(ee[q][0], ee[q][1]);
+      } else if constexpr (st == 2) {
+        ee[q][0] = __builtin_amdgcn_exp2f(ee[q][0]);
+        ee[q][1] = __builtin_amdgcn_exp2f(ee[q][1]);
+        hold2(ee[q][0], ee[q][1]);
+      } else if constexpr (st == 3) {
+        ev[q][0] = ev[q][0] > 0.f ? ev[q][0] : ee[q][0] - 1.0f;
+        hold2(ev[q][0], ee[q][1]);
+      } else if constexpr (st == 4) {
+        ev[q][1] = ev[q][1] > 0.f ? ev[q][1] : ee[q][1] - 1.0f;
+        hold2(ev[q][0], ev[q][1]);
+      } else if constexpr (st == 5) {
+        ev[q][0] *= sC;
+        ev[q][1] *= sC;
+        ehp[q] = pack_f16(ev[q][0], ev[q][1]);
+        hold2(ev[q][0], ev[q][1]);
+        asm volatile("" : "+v"(ehp[q]));
+      } else if constexpr (st == 6) {
+        const f16x2 hh = __builtin_bit_cast(f16x2, ehp[q]);
+        ee[q][0] = (float)hh.x;
+        ee[q][1] = (float)hh.y;
+        hold2(ee[q][0], ee[q][1]);
+      } else {
+        elp[q] = pack_f16((ev[q][0] - ee[q][0]) * 2048.f, (ev[q][1] - ee[q][1]) * 2048.f);
+        asm volatile("" : "+v"(elp[q]));
       }
       BB_PIN;
     };
-    constexpr int MS = (192 + 12 * G2 - 1) / (12 * G2);              // micro-ops per gap (12 gaps per group)
+    constexpr int MS = 64 / (8 * G2) > 0 ? 64 / (8 * G2) : 1;       // micro-steps per gap (8 gaps per group)
+    static_assert(MS * 8 * G2 >= 64, "every micro-step has a gap");
 
     z_req(std::integral_constant<int, ZG1>{});
     stamp(4);
@@ -523,8 +492,8 @@ __global__ __launch_bounds__(256, 1) void proj_fuse_kernel(const B2BArgs G) {
     gemm2(sa_prev, f,
           [&](auto nc, auto kc) __attribute__((always_inline)) {
             bb_static_for<MS>([&](auto uc) __attribute__((always_inline)) {
-              constexpr int o = (decltype(nc)::value * 12 + decltype(kc)::value) * MS + decltype(uc)::value;
-              if constexpr (o < 192) micro(std::integral_constant<int, o>{});
+              constexpr int m = (decltype(nc)::value * 8 + decltype(kc)::value) * MS + decltype(uc)::value;
+              if constexpr (m < 64) micro(std::integral_constant<int, m>{});
             });
           },
           [&](auto nc) __attribute__((always_inline)) {
