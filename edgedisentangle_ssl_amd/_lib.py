@@ -30,6 +30,11 @@ def _hipcc():
     raise RuntimeError("hipcc not found: cannot build libdisgat_hip.so")
 
 
+def _extra_flags():
+    """DISGAT_HIPCC_FLAGS, normalised: what this process expects the library to have been compiled with."""
+    return " ".join(os.environ.get("DISGAT_HIPCC_FLAGS", "").split())
+
+
 def _stale():
     if not os.path.exists(LIB_PATH):
         return True
@@ -63,7 +68,8 @@ def _build_locked(verbose):
     def one(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
         cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
-               *os.environ.get("DISGAT_HIPCC_FLAGS", "").split(),          # e.g. -DNAME for same-box A/B builds (tools/)
+               *_extra_flags().split(),          # e.g. -DNAME for same-box A/B builds (tools/)
+               f'-DDISGAT_BUILD_FLAGS="{_extra_flags()}"',                 # reported by disgat_build_flags()
                "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
@@ -88,6 +94,7 @@ _P = _c.c_void_p
 _SIGS = {
     "disgat_abi_version": (_c.c_int, []),
     "disgat_last_error": (_c.c_char_p, []),
+    "disgat_build_flags": (_c.c_char_p, []),
     "disgat_edge_fwd": (_c.c_int, [_c.c_int, _P, _c.c_int, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
                                    _P, _c.c_int, _P, _c.c_int, _P, _c.c_int, _P, _P, _P, _P, _P, _P, _c.c_int,
                                    _c.c_float, _c.c_uint64, _P, _P, _P, _P, _P, _P, _P]),
@@ -170,6 +177,21 @@ def load():
         lib.disgat_abi_version.restype = _c.c_int
         if lib.disgat_abi_version() != ABI_VERSION:
             raise RuntimeError(f"libdisgat_hip.so reports ABI {lib.disgat_abi_version()}, this package binds ABI {ABI_VERSION}")
+    def flags_of(l):
+        if not hasattr(l, "disgat_build_flags"):
+            return None
+        l.disgat_build_flags.restype = _c.c_char_p
+        return l.disgat_build_flags().decode()
+
+    if flags_of(lib) != _extra_flags():
+        # e.g. a -DRS_DIAG / -DBB_DIAG build a tools/ script left behind: timestamps look fresh, but it is not the library
+        # this process asked for - rebuild with this process's flags, then refuse
+        build(force=True)
+        lib = ctypes.CDLL(LIB_PATH)
+        lib.disgat_abi_version.restype = _c.c_int
+        if lib.disgat_abi_version() != ABI_VERSION or flags_of(lib) != _extra_flags():
+            raise RuntimeError(f"libdisgat_hip.so was compiled with flags {flags_of(lib)!r}, "
+                               f"this process expects {_extra_flags()!r} (DISGAT_HIPCC_FLAGS)")
     for name, (res, args) in _SIGS.items():
         try:
             fn = getattr(lib, name)

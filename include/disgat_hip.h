@@ -80,6 +80,7 @@ extern "C" {
 typedef void* disgat_stream_t; /* hipStream_t */
 
 int disgat_abi_version(void);          /* 9 in this revision; changes with any launcher's argument list */
+const char* disgat_build_flags(void);  /* the -D flags of this build ("" = plain): the host refuses a diagnostic build it did not ask for */
 const char* disgat_last_error(void);
 
 /* Fused score -> sigmoid -> row softmax -> aggregation for all H heads of one layer.

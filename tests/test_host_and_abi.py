@@ -24,6 +24,10 @@ def test_library_builds_loads_and_exports_header_symbols():
     lib.disgat_abi_version.restype = ctypes.c_int
     from edgedisentangle_ssl_amd import _lib as binding
     assert lib.disgat_abi_version() == binding.ABI_VERSION      # the loader rebuilds / refuses a library of another ABI
+    # a diagnostic build (-DRS_DIAG / -DBB_DIAG / -DDISGAT_PL_DIAG: stamps, ablation switches) must not be picked up silently:
+    # the library reports the -D flags it was compiled with; _lib.load() rebuilds on a mismatch with this process's flags
+    lib.disgat_build_flags.restype = ctypes.c_char_p
+    assert lib.disgat_build_flags().decode() == binding._extra_flags() == ""
 
 
 def test_csr_and_work_items_cover_every_edge_once():

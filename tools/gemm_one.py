@@ -3,6 +3,7 @@
   tools/gemm_one.py pq       x [M,256] @ [256,2048]          fp32 operand, A-stationary kernel (P / Q score operands)
   tools/gemm_one.py proj     Z planes [M,8,256] @ [8,256,256] -> ELU -> head planes      (disgat_gemm_planes)
   tools/gemm_one.py fuser    head planes [M,2048] @ [2048,256] + bias, leaky ReLU -> fp32 (disgat_gemm_planes)
+  tools/gemm_one.py b2b      Z planes [M,8,256] @ [8,256,256] -> ELU -> @ [2048,256] + bias, leaky ReLU -> fp32, one launch (disgat_proj_fuse)
   tools/gemm_one.py K N      fp32 operand [M,K] @ [K,N] on the fp32-input kernels (round-2 form)"""
 import os
 import sys
@@ -20,6 +21,15 @@ if what == "proj":
     ap, wr = og.split_planes(a), og.presplit_rm(w)
     bound = (ap.bound * w.abs().sum(1).max()).reshape(1)
     fn = lambda: og.linear_planes(ap, wr, 256, None, None, og.ACT_ELU, 0.0, False, bound)      # noqa: E731
+elif what == "b2b":
+    a = torch.randn(M, 8, 256, device="cuda").permute(1, 0, 2)
+    w1 = torch.randn(8, 256, 256, device="cuda") * 0.05
+    w2 = torch.randn(2048, 256, device="cuda") * 0.02
+    b = torch.randn(256, device="cuda")
+    ap, wch = og.split_planes(a), og.presplit_b2b(w1, w2)
+    del a
+    bound = torch.clamp(ap.bound * w1.abs().sum(1).max() * 1.001, min=1.0).reshape(1)
+    fn = lambda: og.proj_fuse(ap, wch, None, b, bound, 256, 256, og.ACT_LEAKY, 0.01)           # noqa: E731
 elif what == "fuser":
     h = torch.randn(M, 2048, device="cuda")
     w = torch.randn(2048, 256, device="cuda") * 0.02

@@ -9,7 +9,12 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-name = sys.argv[1] if len(sys.argv) > 1 else "chameleon"
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+name = args[0] if args else "chameleon"
+att = sys.argv[sys.argv.index("--att") + 1] if "--att" in sys.argv else "3"        # tools/op_count.py cora --att 2
+if "--att" in sys.argv:
+    args = [a for a in args if a != att]
+    name = args[0] if args else "chameleon"
 from edgedisentangle_ssl_amd import main as drop_in, pretrainer, trainer  # noqa: E402
 
 # build the trainers exactly as main.run does, by running two eager epochs through it with hooks that keep the objects
@@ -22,7 +27,7 @@ for cls in (trainer.ClsTrainer, pretrainer.SupEdgeTrainer, pretrainer.GeneratedE
         return _o(self, *a)
     cls.train_step_captured = wrap
 fx = os.path.join(ROOT, "tests", "golden", f"data_{name}.npz")
-argv = ["--model=DISGAT", "--sparse", "--dataset", name, "--fixture", fx, "--gnn_type", "AT", "--att", "3", "--nhead", "8", "--nhid", "64",
+argv = ["--model=DISGAT", "--sparse", "--dataset", name, "--fixture", fx, "--gnn_type", "AT", "--att", att, "--nhead", "8", "--nhid", "64",
         "--steps", "1", "--downstream", "CLS", "--down_weight", "1.0", "--finetune", "--pretrain", "SupEdge", "DisEdge", "DifHead",
         "--pre_weight", "1", "1", "1", "--pre_edge", "1", "1", "1", "--dropout", "0.1", "--seed", "4", "--quiet", "--epochs", "2", "--capture", "on"]
 drop_in.run(argv)
