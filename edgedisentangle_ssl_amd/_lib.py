@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libdisgat_hip.so")
 SOURCES = ["api_common.hip", "edge_fwd.hip", "aux_score.hip", "edge_bwd.hip", "gemm_split.hip", "gemm_rs.hip", "gemm_planes.hip", "gemm_b2b.hip", "linear_skinny.hip",
            "optim.hip", "pair_sample.hip", "seg_tables.hip", "cls_loss.hip", "wgrad_small.hip"]
 ARCH = "gfx950"
-ABI_VERSION = 9         # csrc/api_common.hip: bumped whenever a launcher's argument list changes (round 3: dropout seed
+ABI_VERSION = 10        # csrc/api_common.hip: bumped whenever a launcher's argument list changes (round 3: dropout seed
                         # counter, padding labels / items, score-gradient strides, amax outputs, plane outputs; round 4: pair sampler, classification loss, small weight gradients)
 
 _lib = None
@@ -133,6 +133,8 @@ _SIGS = {
     "disgat_gemm_planes": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _P, _P, _P, _P, _P, _c.c_int64, _c.c_int64, _P,
                                       _c.c_int64, _c.c_int64, _P, _P, _c.c_int64, _c.c_int64, _P, _c.c_int, _c.c_int,
                                       _c.c_int, _c.c_int, _c.c_int, _c.c_float, _P]),
+    "disgat_gemm_planes_logits": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _P, _P, _P, _P, _P, _c.c_int64, _c.c_int64, _P, _P, _P,
+                                             _P, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_float, _P]),
     "disgat_proj_fuse": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _c.c_int64, _c.c_int, _c.c_int,
                                     _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_float, _P]),
     "disgat_split_planes": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _P, _P, _P, _c.c_int64,

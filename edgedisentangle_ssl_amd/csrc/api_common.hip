@@ -7,7 +7,7 @@ char* err_buf() {
 }
 }  // namespace disgat
 
-extern "C" int disgat_abi_version(void) { return 9; }     // == _lib.ABI_VERSION: bumped with every argument-list change
+extern "C" int disgat_abi_version(void) { return 10; }     // == _lib.ABI_VERSION: bumped with every argument-list change
 // the -D... flags this library was compiled with (_lib.py: DISGAT_HIPCC_FLAGS; "" for a plain build): a diagnostic build
 // (-DRS_DIAG, -DBB_DIAG, -DDISGAT_PL_DIAG: stamps, ablation switches) left in the tree is recognised and rebuilt by
 // _lib.load() instead of being benchmarked silently

@@ -51,6 +51,12 @@ struct GemmPArgs {
   float slope;
   int nsteps, units;       // column steps of 256; units = row tiles x nsteps x batch
   int dbg;                 // switches (DISGAT_PL_DEBUG): 64 = round 3's unit map; with DISGAT_PL_DIAG: 1 no stores, 2 no MFMA, 4 A rows from a cache-resident range
+  // LG variant (disgat_gemm_planes_logits): a second, skinny product in the epilogue - L = act(.) W2 + b2, N = 256 -> n_out <= 16
+  const uint16_t* W2f;     // fragment image of W2 * s_W2: [8 groups of 32 rows][2 planes][64 lanes][8 halfs]
+  const float* w2_scale;   // device scalar s_W2
+  const float* bias2;      // [16] (zero past n_out) or null
+  float* L;                // [M * batch][n_out]: row (m, b) at (m * batch + b) * n_out
+  int n_out;
 };
 
 constexpr int PL_BM = 128, PL_BN = 256;
@@ -87,8 +93,11 @@ __device__ __forceinline__ void static_for(F&& f) {
   static_for_impl(std::make_integer_sequence<int, N>{}, f);
 }
 
-template <int ACT, bool F32, bool PL>
+constexpr int PL_LG_LDS = 4 * PL_BM * 16 * 4;     // LG: per column strip (wn) and row 16 partial outputs, fp32
+
+template <int ACT, bool F32, bool PL, bool LG = false>
 __global__ __launch_bounds__(512, 1) void gemm_planes_kernel(const GemmPArgs G) {
+  static_assert(!LG || (!F32 && !PL), "the logits variant has no other output");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_pl[];
   constexpr int NSA = 3, NSB = 2;                           // ring slots: A two k-steps ahead, weights one
   constexpr int MC = 5, ML = 3;                             // 16-row tiles of a compute wave / of a loader wave
@@ -118,7 +127,36 @@ __global__ __launch_bounds__(512, 1) void gemm_planes_kernel(const GemmPArgs G) 
   const float inv = 1.0f / sAB;
   const float xw = inv * (1.0f / 2048.f);
   float sC = 1.0f;
-  if constexpr (PL) sC = f16_scale(*G.c_bound);
+  if constexpr (PL || LG) sC = f16_scale(*G.c_bound);
+  // LG: the unit's activated [128 x 256] tile is the B operand of a second f16x3 product with W2 (transposed form again: a
+  // lane's 8 consecutive columns of one row ARE its 8 k-values of a 16x16x32 fragment).  Each wave's 64-column strip gives a
+  // partial [rows x 16] result; the four strips meet in LDS and are summed, in strip order, after the next barrier.
+  float* const lg_part = reinterpret_cast<float*>(lds_pl + NSA * PL_A_SLOT + NSB * PL_B_SLOT);
+  int pend_m0 = -1, pend_bz = 0;
+  auto lg_reduce = [&](int m0, int bz) __attribute__((always_inline)) {
+    const int row = threadIdx.x >> 2, qq = threadIdx.x & 3;
+    f32x4 s = *reinterpret_cast<const f32x4*>(lg_part + (0 * PL_BM + row) * 16 + 4 * qq);
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const f32x4 p = *reinterpret_cast<const f32x4*>(lg_part + (w * PL_BM + row) * 16 + 4 * qq);
+      s = f32x4{s.x + p.x, s.y + p.y, s.z + p.z, s.w + p.w};
+    }
+    if (G.bias2 != nullptr) {
+      const f32x4 b = ld4(G.bias2 + 4 * qq);
+      s = f32x4{s.x + b.x, s.y + b.y, s.z + b.z, s.w + b.w};
+    }
+    if (m0 + row < G.M && 4 * qq < G.n_out) {
+      float* lp = G.L + ((int64_t)(m0 + row) * G.batch + bz) * G.n_out + 4 * qq;
+      if ((G.n_out & 3) == 0) {
+        st4(lp, s);
+      } else {
+        const float v[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (4 * qq + r < G.n_out) lp[r] = v[r];
+      }
+    }
+  };
 
   auto decode = [&](int u, int& m0, int& n0, int& bz) __attribute__((always_inline)) {
     int r;
@@ -269,6 +307,11 @@ __global__ __launch_bounds__(512, 1) void gemm_planes_kernel(const GemmPArgs G) 
       __builtin_amdgcn_s_barrier();
       stamp(1);
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (LG) {
+        // the previous unit's partial results are all in LDS (its epilogue's ds_writes were waited for above, the barrier
+        // says: by every wave); this unit's epilogue writes them again only after KT more barriers
+        if (t == 0 && pend_m0 >= 0) lg_reduce(pend_m0, pend_bz);
+      }
       if (ld_wave) {
         issue_b();
         issue_a();
@@ -332,11 +375,26 @@ __global__ __launch_bounds__(512, 1) void gemm_planes_kernel(const GemmPArgs G) 
       relax = false;
       continue;
     }
+    // LG: this wave's two fragments of W2 (rows wn * 64 + 32 g + 8 q .. + 7, output lane & 15), both planes - 16 KB image in
+    // L2, fetched per unit so that nothing of it is live across the k-loop (the kernel sits at the 256-register limit)
+    f16x8 w2h[2], w2l[2];
+    float inv2 = 0.f, xw2 = 0.f;
+    if constexpr (LG) {
+      const uint16_t* wf = G.W2f + ((size_t)(wn * 2) * 2 * 64 + lane) * 8;
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        w2h[g] = *reinterpret_cast<const f16x8*>(wf + (size_t)(g * 2 + 0) * 64 * 8);
+        w2l[g] = *reinterpret_cast<const f16x8*>(wf + (size_t)(g * 2 + 1) * 64 * 8);
+      }
+      inv2 = 1.0f / (sC * *G.w2_scale);
+      xw2 = inv2 * (1.0f / 2048.f);
+    }
     auto epi = [&](auto lo_c, auto hi_c) __attribute__((always_inline)) {
 #pragma unroll
       for (int i = decltype(lo_c)::value; i < decltype(hi_c)::value; ++i) {
         const int row = row0 + 16 * i;
         const bool ok = (full || row < G.M) && !(DISGAT_PL_DIAG && (G.dbg & 8));
+        f32x4v lacc = f32x4v{0.f, 0.f, 0.f, 0.f}, lacx = f32x4v{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
           float v[8];
@@ -344,6 +402,16 @@ __global__ __launch_bounds__(512, 1) void gemm_planes_kernel(const GemmPArgs G) 
           for (int r = 0; r < 4; ++r) {
             v[r] = act_ct<ACT>(fmaf(acx[i][2 * g][r], xw, acc[i][2 * g][r] * inv), G.slope);
             v[4 + r] = act_ct<ACT>(fmaf(acx[i][2 * g + 1][r], xw, acc[i][2 * g + 1][r] * inv), G.slope);
+          }
+          if constexpr (LG) {
+            u32x2 h0, l0, h1, l1;
+            split4h(f32x4{v[0], v[1], v[2], v[3]} * sC, h0, l0);
+            split4h(f32x4{v[4], v[5], v[6], v[7]} * sC, h1, l1);
+            const f16x8 th = __builtin_bit_cast(f16x8, u32x4{h0.x, h0.y, h1.x, h1.y});
+            const f16x8 tl = __builtin_bit_cast(f16x8, u32x4{l0.x, l0.y, l1.x, l1.y});
+            lacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2h[g], th, lacc, 0, 0, 0);
+            lacx = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2l[g], th, lacx, 0, 0, 0);
+            lacx = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2h[g], tl, lacx, 0, 0, 0);
           }
           if constexpr (F32) {
             float* cp = G.C + (int64_t)bz * G.c_bs + (int64_t)row * G.ldc + col0 + 32 * g;
@@ -363,12 +431,29 @@ __global__ __launch_bounds__(512, 1) void gemm_planes_kernel(const GemmPArgs G) 
             }
           }
         }
+        if constexpr (LG) {
+          // lane (n = lane & 15, q): outputs 4 q .. 4 q + 3 of row wrow + 16 i + n, this strip's share
+          const f32x4 pv = {fmaf(lacx[0], xw2, lacc[0] * inv2), fmaf(lacx[1], xw2, lacc[1] * inv2),
+                            fmaf(lacx[2], xw2, lacc[2] * inv2), fmaf(lacx[3], xw2, lacc[3] * inv2)};
+          *reinterpret_cast<f32x4*>(lg_part + (wn * PL_BM + wrow + 16 * i + (lane & 15)) * 16 + 4 * q) = pv;
+        }
       }
     };
     epi(std::integral_constant<int, 0>{}, std::integral_constant<int, ML>{});
     if (!ld_wave) epi(std::integral_constant<int, ML>{}, std::integral_constant<int, MC>{});
     relax = full;       // a ragged tile may have skipped store instructions: the next unit counts strictly
+    if constexpr (LG) {
+      pend_m0 = m0;
+      pend_bz = bz;
+    }
     stamp(4);
+  }
+  if constexpr (LG) {
+    if (pend_m0 >= 0) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      lg_reduce(pend_m0, pend_bz);
+    }
   }
   // the ring still holds DMAs in flight (re-loads of the last unit): they must land before the block's LDS is released
   wait_vm<0>();
@@ -433,11 +518,11 @@ static int n_cus() {
   return n;
 }
 
-template <int ACT, bool F32, bool PL>
+template <int ACT, bool F32, bool PL, bool LG = false>
 static int launch_planes_ring(int, const GemmPArgs& G, hipStream_t st) {
-  constexpr int lds_bytes = 3 * PL_A_SLOT + 2 * PL_B_SLOT;
+  constexpr int lds_bytes = 3 * PL_A_SLOT + 2 * PL_B_SLOT + (LG ? PL_LG_LDS : 0);
   static bool set = false;
-  auto fn = gemm_planes_kernel<ACT, F32, PL>;
+  auto fn = gemm_planes_kernel<ACT, F32, PL, LG>;
   if (!set) {
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e != hipSuccess) return fail((int)e, "gemm_planes: cannot reserve %d B of LDS: %s", lds_bytes, hipGetErrorString(e));
@@ -489,6 +574,40 @@ extern "C" int disgat_gemm_planes(const uint16_t* A_hi, const uint16_t* A_lo, in
   if (act == 1) return launch_planes_out<1>(f32, pl, nsa, G, st);
   if (act == 2) return launch_planes_out<2>(f32, pl, nsa, G, st);
   return launch_planes_out<0>(f32, pl, nsa, G, st);
+}
+
+// The DifHead classifier on the head planes (pretrainer.py:819-832 over models.py:523-543 with cls_layer == 2):
+//   L[(m, b)][:] = act( A[b][m][:] W1[b] + bias + init[m][:] ) W2 + bias2          N = 256 hidden columns, n_out <= 16
+// The hidden layer ([M x batch, 256] fp32: 8.2 GB at M = 1e6, batch = 8) is neither written nor read back: its tiles
+// become the operand of the second product while they are still in the accumulators (gemm_planes_kernel<.., LG = true>).
+extern "C" int disgat_gemm_planes_logits(const uint16_t* A_hi, const uint16_t* A_lo, int64_t lda, int64_t a_batch_stride,
+                                         const uint16_t* Bt_planes, const float* a_bound, const float* b_scale,
+                                         const float* bias, const float* init, int64_t ldi, int64_t init_batch_stride,
+                                         const float* mid_bound, const uint16_t* W2_frags, const float* w2_scale,
+                                         const float* bias2, float* L, int M, int N, int K, int batch, int n_out, int act,
+                                         float slope, disgat_stream_t stream) {
+  using namespace disgat;
+  if (M == 0 || batch == 0) return 0;
+  DISGAT_REQUIRE(A_hi && A_lo && Bt_planes && a_bound && b_scale && mid_bound && W2_frags && w2_scale && L && M > 0 && batch > 0,
+                 "gemm_planes_logits: null pointer / bad sizes");
+  DISGAT_REQUIRE(N == PL_BN && K >= 64 && K % 32 == 0, "gemm_planes_logits: N=%d must be %d, K=%d a multiple of 32 and >= 64", N, PL_BN, K);
+  DISGAT_REQUIRE(n_out >= 1 && n_out <= 16, "gemm_planes_logits: n_out=%d must be in 1..16", n_out);
+  DISGAT_REQUIRE(lda % 8 == 0 && a_batch_stride % 8 == 0 && aligned16(A_hi) && aligned16(A_lo) && aligned16(Bt_planes) && aligned16(W2_frags),
+                 "gemm_planes_logits: plane rows must be 16-byte aligned (lda, batch stride multiples of 8 halfs)");
+  DISGAT_REQUIRE(!init || (ldi % 4 == 0 && init_batch_stride % 4 == 0 && aligned16(init)), "gemm_planes_logits: init rows must be 16-byte aligned");
+  DISGAT_REQUIRE((!bias || aligned16(bias)) && (!bias2 || aligned16(bias2)) && ((n_out & 3) != 0 || aligned16(L)),
+                 "gemm_planes_logits: bias, bias2 (16 floats) and L must be 16-byte aligned");
+  DISGAT_REQUIRE(act >= 0 && act <= 2, "gemm_planes_logits: act must be 0 (none), 1 (elu) or 2 (leaky relu)");
+  const int mt = (M + PL_BM - 1) / PL_BM;
+  const int64_t units = (int64_t)mt * batch;
+  DISGAT_REQUIRE(units < ((int64_t)1 << 31) && (int64_t)M * batch < ((int64_t)1 << 31), "gemm_planes_logits: too many tiles / rows");
+  GemmPArgs G{A_hi, A_lo, lda, a_batch_stride, Bt_planes, a_bound, b_scale, bias, init, ldi, init_batch_stride,
+              nullptr, 0, 0, nullptr, nullptr, 0, 0, mid_bound, M, N, K, batch, slope, 1, (int)units,
+              getenv("DISGAT_PL_DEBUG") ? atoi(getenv("DISGAT_PL_DEBUG")) : 0, W2_frags, w2_scale, bias2, L, n_out};
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (act == 1) return launch_planes_ring<1, false, false, true>(0, G, st);
+  if (act == 2) return launch_planes_ring<2, false, false, true>(0, G, st);
+  return launch_planes_ring<0, false, false, true>(0, G, st);
 }
 
 extern "C" int disgat_debug_stamps(unsigned long long* out16, int reset) {

@@ -260,6 +260,58 @@ def linear_planes(ap, w_rm, n, bias=None, init=None, act=ACT_NONE, slope=0.01, w
     return out, (None if oh is None else Planes(oh, ol, out_bound))
 
 
+def logits_ok(k, n_hidden, n_out):
+    """Shapes disgat_gemm_planes_logits takes (DISGAT_LOGITS=0: the two-launch form, same-box A/B)."""
+    return planes_ok(k, n_hidden) and n_hidden == 256 and 1 <= n_out <= 16 and os.environ.get("DISGAT_LOGITS", "1") != "0"
+
+
+def presplit_logits(w2, b2):
+    """nn.Linear(256 -> n_out) weight [n_out, 256] (+ bias) as the MFMA fragment image disgat_gemm_planes_logits reads:
+    (int16 [8, 2, 64, 8], device scalar s_W2, fp32 [16] bias or None, n_out).  Pure tensor ops, no host read."""
+    w2 = w2.detach()
+    n_out, k = w2.shape
+    wt = torch.zeros((16, k), dtype=torch.float32, device=w2.device)
+    wt[:n_out] = w2
+    amax_w = wt.abs().max()
+    _, e = torch.frexp(amax_w)                                             # gemm_common.h: f16_scale()
+    s = torch.where((amax_w > 0) & torch.isfinite(amax_w), torch.ldexp(torch.ones_like(amax_w), 14 - e.clamp(-100, 100)),
+                    torch.ones_like(amax_w))
+    t = wt * s
+    hi = t.to(torch.float16)
+    lo = ((t - hi.float()) * 2048.0).to(torch.float16)
+    # [p][o][k] -> [g = k / 32][p][lane = 16 (k % 32 / 8) + o][e = k % 8]
+    img = torch.stack([hi, lo]).view(2, 16, k // 32, 4, 8).permute(2, 0, 3, 1, 4).contiguous().view(k // 32, 2, 64, 8)
+    bias = None
+    if b2 is not None:
+        bias = torch.zeros(16, dtype=torch.float32, device=w2.device)
+        bias[:n_out] = b2.detach()
+    return img.view(torch.int16), s.reshape(1), bias, n_out
+
+
+def linear_planes_logits(ap, w_rm, bias, init, act, slope, mid_bound, w2_prep):
+    """act(A @ W1 + bias + init) @ W2^T + b2 in one launch, A given as head-batched Planes [H, M, K]; returns fp32
+    [M * H, n_out], row (m, h) at m * H + h.  w_rm = presplit_rm(W1 [H, K, 256]), w2_prep = presplit_logits(...)."""
+    batched = ap.dim() == 3
+    hb, m, k = (ap.shape if batched else (1,) + tuple(ap.shape))
+    planes, b_scale = w_rm
+    img, s2, bias2, n_out = w2_prep
+    n = 256
+    out = torch.empty((m * hb, n_out), dtype=torch.float32, device=ap.hi.device)
+    init_bs = n if batched else 0
+    if init is not None and batched and init.shape == (m, n) and init.stride(-1) == 1:
+        init_bs = 0
+    elif init is not None and (init.stride(-1) != 1 or tuple(init.shape) != (m, hb * n)):
+        init = init.expand(m, hb * n).contiguous()
+    if bias is not None:
+        bias = bias.contiguous()
+    ops._launch("disgat_gemm_planes_logits", "gemm_f16x3", 2.0 * m * hb * (n * k + n * 16),
+                ap.hi.data_ptr(), ap.lo.data_ptr(), ap.hi.stride(-2), ap.hi.stride(0) if batched else 0, planes.data_ptr(),
+                ap.bound.data_ptr(), b_scale.data_ptr(), ops._ptr(bias), ops._ptr(init),
+                0 if init is None else init.stride(0), init_bs, mid_bound.data_ptr(), img.data_ptr(), s2.data_ptr(),
+                ops._ptr(bias2), out.data_ptr(), m, n, k, hb, n_out, act, float(slope), ops._stream())
+    return out
+
+
 _KPAD = {}          # (data_ptr, version, shape) -> (tensor kept alive, zero-padded copy): padded copies of constant operands
 
 

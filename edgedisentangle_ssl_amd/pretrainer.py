@@ -422,13 +422,26 @@ class DifHeadTrainer(Trainer):
                 f_in = inp.shape[1]
                 shared = ops_gemm.linear(inp, lin.weight[:, :f_in].t(), lin.bias)
                 w_h = lin.weight[:, f_in:].t().unsqueeze(0).expand(nh, fo, -1)
-                if fused is None:      # no-graph forward: the head buffer exists only as the GEMM's operand planes
+                if (fused is None and len(mods) == 3 and isinstance(mods[2], torch.nn.Linear)
+                        and ops_gemm.logits_ok(fo, lin.out_features, mods[2].out_features)):
+                    # no-graph forward, hidden -> logits in the hidden layer's epilogue (disgat_gemm_planes_logits): the
+                    # [N * nhead, hidden] activations (8 GB at 1M nodes) are neither written nor read back
+                    from .layers import _memo
+                    w_rm, w2p, wnorm = _memo([classifier], "difhead_logits", lambda: (
+                        ops_gemm.presplit_rm(w_h), ops_gemm.presplit_logits(mods[2].weight, mods[2].bias),
+                        ops_gemm.weight_bound(lin.weight[:, f_in:].t())[0]))
+                    mid_bound = (planes.bound.reshape(-1)[0] * wnorm * 1.001 + ops_gemm.amax(shared).reshape(-1)[0]).reshape(1)
+                    t = ops_gemm.linear_planes_logits(planes.view_heads(nh), w_rm, None, shared, ops_gemm.ACT_LEAKY,
+                                                      mods[1].negative_slope, mid_bound, w2p)
+                    mods = mods[:2]         # nothing left to apply below
+                elif fused is None:    # no-graph forward: the head buffer exists only as the GEMM's operand planes
                     t = ops_gemm.linear_planes(planes.view_heads(nh), ops_gemm.presplit_rm(w_h), lin.out_features, None, shared,
                                                ops_gemm.ACT_LEAKY, mods[1].negative_slope)[0]
                 else:
                     t = ops_gemm.linear(fused.view(-1, nh, fo).permute(1, 0, 2), w_h, None, shared, ops_gemm.ACT_LEAKY,
                                         mods[1].negative_slope, a_amax=getattr(heads, "fused_amax", None))   # [N, H*hidden]
-                t = t.view(t.shape[0] * nh, -1)
+                if len(mods) > 2:
+                    t = t.view(t.shape[0] * nh, -1)
                 for m in mods[2:]:
                     # hidden -> nhead logits on N * nhead rows: 1 KB read per 32 B written (ops_gemm.skinny_linear)
                     t = ops_gemm.skinny_linear(t, m) if isinstance(m, torch.nn.Linear) and ops_gemm.skinny_ok(t, m) else m(t)

@@ -79,7 +79,7 @@ extern "C" {
 
 typedef void* disgat_stream_t; /* hipStream_t */
 
-int disgat_abi_version(void);          /* 9 in this revision; changes with any launcher's argument list */
+int disgat_abi_version(void);          /* 10 in this revision; changes with any launcher's argument list */
 const char* disgat_build_flags(void);  /* the -D flags of this build ("" = plain): the host refuses a diagnostic build it did not ask for */
 const char* disgat_last_error(void);
 
@@ -324,6 +324,22 @@ int disgat_gemm_planes(const uint16_t* A_hi, const uint16_t* A_lo, int64_t lda, 
                        int64_t c_batch_stride, uint16_t* C_hi, uint16_t* C_lo, int64_t ldp, int64_t p_batch_stride,
                        const float* c_bound, int M, int N, int K, int batch, int act, float slope,
                        disgat_stream_t stream);
+
+/* disgat_gemm_planes followed by a skinny second product in the same launch - the DifHead classifier on the head planes
+ * (pretrainer.py:819-832: MLP(cat(layer_in, head_out_i)) per head i; models.py:523-543 with cls_layer == 2):
+ *   L[(m, b)][0 .. n_out) = act( A[b][m][:] W1[b] + bias + init[m][:] ) W2 + bias2         N == 256, 1 <= n_out <= 16
+ * The hidden layer ([M * batch][256]) exists only as accumulator tiles: each becomes the operand of the second f16x3
+ * product while it is still in registers.  mid_bound: device scalar >= max |act(.)| (e.g. a_bound x the largest column
+ * abs-sum of W1 + max |init| + max |bias|).  W2_frags: W2 * s_W2 as MFMA fragments, [8 groups of 32 hidden columns][2 planes:
+ * hi, lo][64 lanes][8 halfs], lane l of group g holding hidden columns 32 g + 8 (l / 16) .. + 7 of output l % 16 (zero past
+ * n_out); w2_scale: device scalar s_W2; bias2: 16 floats (zero past n_out) or NULL.  L: fp32, row (m, b) at
+ * (m * batch + b) * n_out - the order of the reference's per-head concatenation viewed as [M * nhead, hidden].
+ * Replaces nn.Linear -> LeakyReLU -> nn.Linear of models.py:538 on no-graph forwards. */
+int disgat_gemm_planes_logits(const uint16_t* A_hi, const uint16_t* A_lo, int64_t lda, int64_t a_batch_stride,
+                              const uint16_t* Bt_planes, const float* a_bound, const float* b_scale, const float* bias,
+                              const float* init, int64_t ldi, int64_t init_batch_stride, const float* mid_bound,
+                              const uint16_t* W2_frags, const float* w2_scale, const float* bias2, float* L, int M, int N,
+                              int K, int batch, int n_out, int act, float slope, disgat_stream_t stream);
 
 /* The per-head output projection AND the FuseLayer that consumes it as ONE launch (back-to-back GEMM; no-graph forwards):
  *   C = act2( cat_h [ elu( Z_h W1_h + bias1_h ) ] W2 + bias2 )

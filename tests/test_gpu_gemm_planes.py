@@ -50,6 +50,53 @@ def test_planes_gemm_vs_float64(m, hb, k, n, act, bias, init, planes_out):
         assert only_pl[0] is None and torch.equal(only_pl[1].hi, pl.hi) and torch.equal(only_pl[1].lo, pl.lo)
 
 
+@pytest.mark.parametrize("m,hb,k,n_out,act,bias,init,bias2", [
+    (5000, 8, 256, 8, 2, False, "shared", True), (70001, 8, 256, 8, 2, False, "shared", True), (1, 0, 64, 8, 2, True, None, False),
+    (129, 4, 128, 16, 1, True, "full", True), (1000, 3, 256, 5, 0, False, None, True), (257, 8, 256, 1, 2, False, "shared", False),
+    (12345, 2, 512, 12, 2, True, "shared", True)])
+def test_planes_gemm_with_logits_epilogue_vs_float64(m, hb, k, n_out, act, bias, init, bias2):
+    """disgat_gemm_planes_logits: L = act(A W1 + bias + init) W2^T + b2 without the hidden layer in memory - against float64
+    and against the two-launch form (plane GEMM -> fp32 hidden -> skinny product) it replaces; ragged row counts (partial
+    last tile), one row, odd head counts, every n_out class (vector and scalar stores), rows spanning 2^8 in magnitude."""
+    from edgedisentangle_ssl_amd import ops_gemm as og
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cuda").manual_seed(7 * m + k + n_out)
+    H = max(hb, 1)
+    z = torch.randn(m, H, k, device=dev, generator=g) * torch.exp2(4 * torch.rand(m, 1, 1, device=dev, generator=g) - 2)
+    a = z.permute(1, 0, 2) if hb else z[:, 0]
+    w1 = torch.randn(H, k, 256, device=dev, generator=g) * (1.0 / k ** 0.5)
+    if not hb:
+        w1 = w1[0]
+    b1 = torch.randn(H * 256, device=dev, generator=g) * 0.3 if bias else None
+    ini = {None: None, "shared": torch.randn(m, 256, device=dev, generator=g), "full": torch.randn(m, H * 256, device=dev, generator=g)}[init]
+    lin2 = torch.nn.Linear(256, n_out, bias=bias2).to(dev)
+    with torch.no_grad():
+        lin2.weight.copy_(torch.randn(n_out, 256, device=dev, generator=g) * 0.2)
+    hid = torch.bmm(a.double(), w1.double()).permute(1, 0, 2).reshape(m, H * 256) if hb else a.double() @ w1.double()
+    if b1 is not None:
+        hid = hid + b1.double()
+    if ini is not None:
+        hid = hid + (ini.double() if init == "full" else ini.double().repeat(1, H))
+    hid = _ref_act(hid, act)
+    ref = hid.reshape(m * H, 256) @ lin2.weight.detach().double().t() + (lin2.bias.detach().double() if bias2 else 0.0)
+    ap = og.split_planes(a)
+    w_rm = og.presplit_rm(w1)
+    mid = (hid.abs().max().float() * 1.01).reshape(1)
+    out = og.linear_planes_logits(ap, w_rm, b1, ini, act, 0.01, mid, og.presplit_logits(lin2.weight, lin2.bias))
+    assert out.shape == (m * H, n_out)
+    two = og.linear_planes(ap, w_rm, 256, b1, ini, act, 0.01)[0].view(m * H, 256)
+    with torch.no_grad():
+        two = og.skinny_linear(two, lin2) if og.skinny_ok(two, lin2) else lin2(two)
+    # per row: the error relative to sum_k |hidden_k| |w_k| (what an fp32 dot product of that row is held to)
+    scale = (hid.reshape(m * H, 256).abs() @ lin2.weight.detach().double().abs().t()).clamp_min(1e-30)
+    e_new = float(((out.double() - ref).abs() / scale).max())
+    e_two = float(((two.double() - ref).abs() / scale).max())
+    assert e_new <= max(2.0 * e_two, 4e-7), (e_new, e_two)
+    # a looser hand-over bound (the analytic one of the caller) costs nothing visible: fp16 hi + lo carry 22 bits
+    out8 = og.linear_planes_logits(ap, w_rm, b1, ini, act, 0.01, mid * 8.0, og.presplit_logits(lin2.weight, lin2.bias))
+    assert float(((out8.double() - ref).abs() / scale).max()) <= max(2.0 * e_two, 4e-7)
+
+
 def test_plane_output_feeds_the_next_gemm():
     """projection -> ELU -> planes -> fuser, the layer's dense chain: the second GEMM consumes what the first one's
     epilogue wrote, with the analytic bound (input bound x largest column abs-sum) as the hand-over scale."""
@@ -187,12 +234,13 @@ def test_plane_chain_meets_a_reference_output(gnn, att, golden_dir):
             sup_t, dis_t, dif_t = _trainers(a, enc, 400, dev)
             l_sup = sup_t.loss((x, adj), sup[1], [sup[0]])
             l_dis = dis_t.loss((x, adj), [ho[1], he[1]], [ho[0], he[0]])
-            before = calls.get("disgat_gemm_planes", 0)
+            before = calls.get("disgat_gemm_planes", 0) + calls.get("disgat_gemm_planes_logits", 0)
             l_dif = dif_t.loss((x, adj))
-            n_dif = calls.get("disgat_gemm_planes", 0) - before
+            n_dif = calls.get("disgat_gemm_planes", 0) + calls.get("disgat_gemm_planes_logits", 0) - before
     finally:
         _lib.call = real_call
     assert n_planes >= 2 * 4 and n_dif >= 6, calls           # forward + get_em: projection and fuser of both layers; DifHead: + classifier
+    assert calls.get("disgat_gemm_planes_logits", 0) == 2, calls     # ... whose hidden layer goes straight into the logits (both layers)
     for key, t in (("forward", fwd), ("get_em_0", em[0]), ("get_em_1", em[1])):
         close(t[:256], g[key + "_head"], what=f"{key} head rows")
         scale = max(1.0, float(g[key + "_abssum"]) / t.numel() * 50)
