@@ -496,10 +496,15 @@ def small_graph_epochs(att=3, eager=True):
             return (time.perf_counter() - t0) * 1e3
 
         try:
-            drop_in.run(argv + ["--epochs", "2"])          # warm-up: library load, hipBLASLt heuristics
+            # warm-up: library load, hipBLASLt heuristics - and the process's first HIP-graph capture / instantiation, which
+            # on a fresh box can take seconds (one run of round 5 charged 4.1 s of it to chameleon's 8-epoch run and
+            # reported a negative epoch)
+            drop_in.run(argv + ["--epochs", "2", "--capture", "on"])
             # the two runs' fixed parts (load, build, warm-up, capture: ~0.4 s) differ by tens of ms from call to call: over 60
             # epochs that was +-1 ms on a 7 ms epoch, over 240 it is +-0.2
             t8, t248 = timed(8, "on"), timed(248, "on")
+            if t248 - t8 < 0.5 * t8:       # an 8-epoch run that absorbed a one-off stall: take it again
+                t8 = min(t8, timed(8, "on"))
             res[name] = round((t248 - t8) / 240, 2)
             detail[name] = {"first_8_epochs_ms_per_epoch": round(t8 / 8, 1)}
             if eager:
