@@ -14,6 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libdisgat_hip.so")
+FLAGS_PATH = LIB_PATH + ".flags"        # the -D flags the installed library was compiled with (disgat_build_flags() reports the same)
 SOURCES = ["api_common.hip", "edge_fwd.hip", "aux_score.hip", "edge_bwd.hip", "gemm_split.hip", "gemm_rs.hip", "gemm_planes.hip", "gemm_b2b.hip", "linear_skinny.hip",
            "optim.hip", "pair_sample.hip", "seg_tables.hip", "cls_loss.hip", "wgrad_small.hip"]
 ARCH = "gfx950"
@@ -37,6 +38,11 @@ def _extra_flags():
 
 def _stale():
     if not os.path.exists(LIB_PATH):
+        return True
+    try:
+        if open(FLAGS_PATH).read() != _extra_flags():       # e.g. a diagnostic build a tools/ script left behind
+            return True
+    except OSError:
         return True
     t = os.path.getmtime(LIB_PATH)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(_HERE, "..", "include", "disgat_hip.h")]
@@ -86,6 +92,8 @@ def _build_locked(verbose):
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
     os.replace(tmp, LIB_PATH)
+    with open(FLAGS_PATH, "w") as f:        # what _stale() compares before the first dlopen (a loaded library cannot be replaced)
+        f.write(_extra_flags())
     return LIB_PATH
 
 

@@ -76,6 +76,14 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void aux_att3_kernel(const AuxArgs
 #pragma unroll
   for (int t = 0; t < KEEP; ++t) keep[t] = 0.f;
   const int g = lane & (G - 1);
+  // What the sign-recording variant costs over the plain one at C4 (52-54 against 44-45 ms per list; round 5, same-box builds,
+  // profiles/r05/sign_record.md): NOT its vector instructions (a hand-laid v_pk_add / v_pk_mul form with 29 % fewer of them:
+  // same time), not its lower occupancy (2 waves per SIMD against 3: a third gather buffer, 6 rows in flight per SIMD as in
+  // the plain variant: same time), not the cache policy of the record store (non-temporal: same time) and not the static
+  // wait counts (the row loads are conditional, so the compiler's vmcnt for the current pair also waits for the prefetch of
+  // the next one; with unconditional loads the counts run one pair ahead: 0.5 ms of 263 per step).  It IS the store: with
+  // the record computed but not written (-DDISGAT_SIGN_NOSTORE) the kernel takes 45.9 ms - 17 GB of writes into a read stream
+  // that already saturates HBM are served at about a third of the read rate.
   auto compute = [&](const f32x4(&q)[QN], int i) {
     const int r = __builtin_amdgcn_readlane(rv, i);
     if (r != cur_r) {  // wave-uniform
@@ -96,7 +104,11 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void aux_att3_kernel(const AuxArgs
       for (int j = 0; j < QN; ++j) acc = dot4_lrelu_sign(a_r[j], p_r[j], q[j], acc, sg, j);
       // every lane stores (whole 64-word rows; the words of unscored heads are never read): a store under
       // `active` also splits the block and costs a second v_max per feature (z no longer known canonical)
+#if defined(DISGAT_SIGN_NOSTORE)     // timing ablation (tools/prof_sign.sh): the record is computed and kept alive, not stored
+      asm volatile("" ::"v"(sg.word()));
+#else
       A.sign[(m0 + i) * 64 + lane] = sg.word();
+#endif
     } else {
 #pragma unroll
       for (int j = 0; j < QN; ++j) acc = dot4_lrelu(a_r[j], p_r[j], q[j], acc);
