@@ -648,7 +648,8 @@ def main():
         nnz_total = float(graph.nnz)
     if rank != 0:
         if world > 1:
-            dist.destroy_process_group()
+            dist.barrier()              # leave together with rank 0 (which still prints the line): no communicator is torn
+            dist.destroy_process_group()    # down under a peer that may yet use it
         return
     assert torch.isfinite(last).all(), "non-finite loss in the timed region"
 
@@ -732,7 +733,9 @@ def main():
     if rehearsal and world > 1:
         out["config"]["rehearsal"] = "all ranks share cuda:0 over gloo: functional check of the N-rank path, NOT a scaling number"
     print(json.dumps(out))
+    sys.stdout.flush()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -30,6 +30,30 @@ def test_library_builds_loads_and_exports_header_symbols():
     assert lib.disgat_build_flags().decode() == binding._extra_flags() == ""
 
 
+def test_a_library_built_with_other_flags_counts_as_stale(monkeypatch):
+    """tools/*_ablate.sh build the library with -D... diagnostics; a later process with other DISGAT_HIPCC_FLAGS (normally
+    none) must rebuild BEFORE its first dlopen - a loaded library cannot be swapped - which _lib decides from the flags file
+    written next to the .so; the library itself reports the same string (checked after loading)."""
+    from edgedisentangle_ssl_amd import _lib
+    _lib.build()
+    assert not _lib._stale() and open(_lib.FLAGS_PATH).read() == ""
+    monkeypatch.setenv("DISGAT_HIPCC_FLAGS", "  -DRS_DIAG=1   -DFOO ")
+    assert _lib._extra_flags() == "-DRS_DIAG=1 -DFOO" and _lib._stale()
+    monkeypatch.delenv("DISGAT_HIPCC_FLAGS")
+    assert not _lib._stale()
+    saved = open(_lib.FLAGS_PATH).read()
+    try:
+        with open(_lib.FLAGS_PATH, "w") as f:
+            f.write("-DBB_DIAG=32")                 # what a diagnostic build leaves behind
+        assert _lib._stale()
+        os.remove(_lib.FLAGS_PATH)                  # an installed library of unknown origin
+        assert _lib._stale()
+    finally:
+        with open(_lib.FLAGS_PATH, "w") as f:
+            f.write(saved)
+    assert not _lib._stale()
+
+
 def test_csr_and_work_items_cover_every_edge_once():
     from edgedisentangle_ssl_amd.graph import CSRGraph
     idx, vals, n = ic.tiny_graph()
