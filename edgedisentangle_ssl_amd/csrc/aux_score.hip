@@ -65,7 +65,7 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void aux_att3_kernel(const AuxArgs
     if (active) {
       const float* qp = A.colop + (size_t)c * A.ld_col + qoff;
 #pragma unroll
-      for (int j = 0; j < QN; ++j) q[j] = ld4(qp + j * G * 4);
+      for (int j = 0; j < QN; ++j) q[j] = ld4g(qp + j * G * 4);
     }
   };
   // scores of the chunk are parked in registers (lane g of a head group keeps the pairs with

@@ -189,6 +189,15 @@ __device__ __forceinline__ float drop_mult(const DropCfg& d, int64_t k, int h, i
 }
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+// gathered operand rows that are read once per use and never hit a cache (8 GB tables, uniformly random rows): A/B builds
+// (-DDISGAT_NT_GATHER=1) fetch them with the non-temporal hint
+__device__ __forceinline__ f32x4 ld4g(const float* p) {
+#ifdef DISGAT_NT_GATHER
+  return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+#else
+  return *reinterpret_cast<const f32x4*>(p);
+#endif
+}
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
 }  // namespace disgat

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(DISGAT_BLOCK, 2) void edge_fwd_kernel(const EdgeFwd
     if constexpr (PQ) {
       const float* qp = A.colop + (size_t)c * A.ld_col + qoff;
 #pragma unroll
-      for (int j = 0; j < QN; ++j) b.q[j] = ld4(qp + j * G * 4);
+      for (int j = 0; j < QN; ++j) b.q[j] = ld4g(qp + j * G * 4);
     } else if constexpr (ATT == 1) {
       b.s2 = A.colop[(size_t)c * A.ld_col + myh];
     }
