@@ -4,6 +4,7 @@
   tools/gemm_one.py proj     Z planes [M,8,256] @ [8,256,256] -> ELU -> head planes      (disgat_gemm_planes)
   tools/gemm_one.py fuser    head planes [M,2048] @ [2048,256] + bias, leaky ReLU -> fp32 (disgat_gemm_planes)
   tools/gemm_one.py b2b      Z planes [M,8,256] @ [8,256,256] -> ELU -> @ [2048,256] + bias, leaky ReLU -> fp32, one launch (disgat_proj_fuse)
+  tools/gemm_one.py logits   head planes [M,8,256] @ [256,256] + shared, leaky ReLU -> @ [256,8] + bias: [8M,8] logits, one launch (disgat_gemm_planes_logits)
   tools/gemm_one.py K N      fp32 operand [M,K] @ [K,N] on the fp32-input kernels (round-2 form)"""
 import os
 import sys
@@ -30,6 +31,15 @@ elif what == "b2b":
     del a
     bound = torch.clamp(ap.bound * w1.abs().sum(1).max() * 1.001, min=1.0).reshape(1)
     fn = lambda: og.proj_fuse(ap, wch, None, b, bound, 256, 256, og.ACT_LEAKY, 0.01)           # noqa: E731
+elif what == "logits":
+    a = torch.randn(M, 8, 256, device="cuda").permute(1, 0, 2)
+    w = (torch.randn(256, 256, device="cuda") * 0.05).unsqueeze(0).expand(8, 256, 256)     # DifHead's classifier: the same weight for every head
+    shared = torch.randn(M, 256, device="cuda")
+    lin2 = torch.nn.Linear(256, 8).cuda()
+    ap, wr, w2 = og.split_planes(a), og.presplit_rm(w), og.presplit_logits(lin2.weight, lin2.bias)
+    del a
+    mid = (ap.bound * w[0].abs().sum(0).max() * 1.001 + shared.abs().max()).reshape(1)
+    fn = lambda: og.linear_planes_logits(ap, wr, None, shared, og.ACT_LEAKY, 0.01, mid, w2)                 # noqa: E731
 elif what == "fuser":
     h = torch.randn(M, 2048, device="cuda")
     w = torch.randn(2048, 256, device="cuda") * 0.02

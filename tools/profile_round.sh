@@ -34,7 +34,7 @@ run sampler_fetch --pmc FETCH_SIZE --output-format csv -d "$OUT/sampler_fetch" -
 run sampler_write --pmc WRITE_SIZE --output-format csv -d "$OUT/sampler_write" -- $S
 fi
 if stage gemm; then
-for what in pq pq_as proj fuser b2b; do
+for what in ${GEMM_SHAPES:-pq pq_as proj fuser b2b logits}; do
   tag="gemm_$what"
   if [ "$what" = pq_as ]; then export DISGAT_GEMM_AS=1; what=pq; else unset DISGAT_GEMM_AS; fi
   run ${tag}_sq1 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_LDS --output-format csv -d "$OUT/${tag}_sq1" -- python3 $ROOT/tools/gemm_one.py $what &&

@@ -84,7 +84,7 @@ def main(src, dst):
     # GEMM PMC
     with open(os.path.join(dst, "gemm_f16x3_pmc.md"), "w") as out:
         P = lambda *a: print(*a, file=out)      # noqa: E731
-        P("# f16x3 GEMM kernels: PMC counters (tools/gemm_one.py pq | proj | fuser | b2b, M = 1,000,000, 4 launches, per-launch averages)\n")
+        P("# f16x3 GEMM kernels: PMC counters (tools/gemm_one.py pq | proj | fuser | b2b | logits, M = 1,000,000, 4 launches, per-launch averages)\n")
         P("Separate rocprofv3 passes per counter set (SQ set 1, SQ set 2, FETCH_SIZE, WRITE_SIZE) plus a kernel-trace pass "
           "for the duration.  SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles; SQ_VALU_MFMA_BUSY_CYCLES "
           "counts cycles (MI355X_MICROARCH.md).\n")
@@ -93,7 +93,8 @@ def main(src, dst):
                 ("pq_as", "the same product on round 3's kernel, gemm_f16x3_as_kernel<0> (A tile in LDS; DISGAT_GEMM_AS=1)", 2.0e6 * 256 * 2048, "gemm_f16x3"),
                 ("proj", "per-head projection, Z planes [1e6,8,256] x [8,256,256] -> ELU -> head planes: gemm_planes_kernel<1,false,true>", 2.0e6 * 8 * 256 * 256, "gemm_planes"),
                 ("fuser", "FuseLayer, head planes [1e6,2048] x [2048,256] + bias, leaky ReLU -> fp32: gemm_planes_kernel<2,true,false>", 2.0e6 * 2048 * 256, "gemm_planes"),
-                ("b2b", "projection + fuser back to back, Z planes [1e6,8,256] -> fp32 [1e6,256] in one launch: proj_fuse_kernel<8,16,false> (csrc/gemm_b2b.hip)", 2.0e6 * 8 * 256 * 256 * 2, "proj_fuse")):
+                ("b2b", "projection + fuser back to back, Z planes [1e6,8,256] -> fp32 [1e6,256] in one launch: proj_fuse_kernel<8,16,false> (csrc/gemm_b2b.hip)", 2.0e6 * 8 * 256 * 256 * 2, "proj_fuse"),
+                ("logits", "DifHead classifier, head planes [1e6,8,256] x [256,256] + shared, leaky ReLU, x [256,8] in the epilogue -> [8e6,8] logits: gemm_planes_kernel<2,false,false,true>", 2.0e6 * 8 * 256 * (256 + 16), "gemm_planes")):
             P(f"\n## {what}\n")
             kt = [r for r in one(os.path.join(src, f"gemm_{shape}_kt")) if kname in r["Name"]]
             dur = None
