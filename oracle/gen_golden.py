@@ -597,8 +597,8 @@ TINY256 = dict(n=2048, e=40960, f=256, nhid=256, heads=4)
 def gen_tiny256():
     """A fixture at a width the plane-operand GEMM chain tiles (nhid 64 on the bundled graphs never engages
     csrc/gemm_planes.hip, so the chain bench.py times had only met the float64 oracle): SURVEY 8(d)'s power-law generator
-    at N = 2 048 / E = 40 960, F_in = nhid = 256, H = 4 - att 3 with AT, SAGE and (round 5) GCN, and the reference's default
-    attention type, att 2, with AT - the reference's five entry points and three losses; 256-row slices, column sums and
+    at N = 2 048 / E = 40 960, F_in = nhid = 256, H = 4 - att 3 with AT, SAGE and (round 5) GCN, the reference's default
+    attention type, att 2, with AT and SAGE, att 1 with GCN - the reference's five entry points and three losses; 256-row slices, column sums and
     strided score samples are kept.  Fixtures already on disk are left alone (they stay byte-identical)."""
     c = TINY256
     n = c["n"]
@@ -611,7 +611,7 @@ def gen_tiny256():
     sup_idx, sup_lab = ic.sample_pairs(81, n, pos, "sup")
     ho_idx, ho_lab = ic.sample_pairs(82, n, homo, "homo")
     he_idx, he_lab = ic.sample_pairs(83, n, het, "het")
-    for gnn, att in (("AT", 3), ("SAGE", 3), ("GCN", 3), ("AT", 2)):
+    for gnn, att in (("AT", 3), ("SAGE", 3), ("GCN", 3), ("AT", 2), ("GCN", 1), ("SAGE", 2)):
         if os.path.exists(os.path.join(GOLD, f"tiny256_{gnn}_att{att}.npz")):
             continue
         full = {}

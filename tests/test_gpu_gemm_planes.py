@@ -187,13 +187,14 @@ def test_foreign_fuser_still_receives_fp32_heads():
     assert all(ln == H for _t, ln in seen) and torch.isfinite(out[1]).all()
 
 
-@pytest.mark.parametrize("gnn,att", [("AT", 3), ("SAGE", 3), ("GCN", 3), ("AT", 2)])
+@pytest.mark.parametrize("gnn,att", [("AT", 3), ("SAGE", 3), ("GCN", 3), ("AT", 2), ("GCN", 1), ("SAGE", 2)])
 def test_plane_chain_meets_a_reference_output(gnn, att, golden_dir):
     """the plane-operand chain (edge pass -> Z planes -> projection -> head planes -> fuser / DifHead
     classifier) never engages at the bundled graphs' nhid = 64, so it had only met the float64 oracle.  tiny256_*.npz holds
     the UNMODIFIED reference's outputs at a width the chain tiles (SURVEY 8(d)'s generator, N = 2 048, F_in = nhid = 256,
     H = 4; oracle/gen_golden.py --only tiny256): the five entry points and the three losses at north_star's 1e-4, with the
-    launchers counted to prove the chain ran.  Round 5: GCN, and att 2 - the reference's argparse default (utils.py:92); for
+    launchers counted to prove the chain ran.  Round 5: GCN, att 2 - the reference's argparse default (utils.py:92) - with AT and
+    SAGE, att 1 with GCN; for
     AT / GCN the projection + fuser pair of forward / get_em / the score entry points is the back-to-back launch
     (disgat_proj_fuse), DifHead keeps the plane GEMMs (its classifier reads the heads too)."""
     import os
