@@ -23,6 +23,10 @@
 // the 2^-11-weighted cross terms), product accumulated transposed (weight fragment as the MFMA's A operand) and the
 // weight rows of a 32-column group permuted on the way into LDS so that a lane ends up with 8 consecutive output
 // columns of one row: one 16-byte store per plane (or two for fp32) per 16 x 32 block.
+// Round 5, LG variant (disgat_gemm_planes_logits; DifHead's classifier): a second, skinny f16x3 product in the epilogue - the
+// unit's activated [128 x 256] tile, still in the accumulators, is split and becomes the operand of `. W2` (256 -> n_out <= 16,
+// one 16-wide MFMA tile); the four 64-column strips of a row meet in 32 KB of LDS behind the ring and are summed in strip order
+// after the next k-step's barrier.  The [M x batch, 256] hidden layer is never written.
 #include "gemm_common.h"
 #include "disgat_api.h"
 #include <stdlib.h>
